@@ -1,0 +1,108 @@
+"""Drop-in ``nn.Module`` surface for the reference's U-Net / U-Net-DC.
+
+Boundary contract:
+  * ``UNetDC(in_channels=3, out_channels=1)``  <-> /root/reference/models/model_2.py:5-32
+  * ``UNet(in_channels=3, out_channels=1)``    <-> /root/reference/models/model.py:7-23
+  * identical 136-key ``state_dict`` (``enc1.0.weight`` ... ``out_conv.bias``), identical default
+    initialisation under a given ``torch.manual_seed`` (same constructors, same order), fp32
+    ``nn.Parameter``s in PyTorch layout so ``torch.optim.Adam(model.parameters())`` works unchanged
+    (train_DC_focal.py:224).
+  * ``forward(x[N,C,H,W] fp32) -> probabilities[N,out,H,W] fp32`` (model_2.py:56-80), autograd
+    capable, ``train()``/``eval()`` switch BatchNorm between batch and running statistics.
+
+On a HIP device every arithmetic op runs in the hand-written gfx950 kernels of
+``csrc/`` through :mod:`unet_dc_segmentation_amd.engine`; there is no PyTorch fallback there -- a
+missing ``libunetdc_hip.so`` raises.  On CPU tensors (the reference's ``DEVICE = "cpu"`` case,
+BASELINE config 0) the module runs the ordinary ATen CPU ops, which is what the reference does
+on a host without a GPU.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+ENCODER = ("enc1", "enc2", "enc3", "enc4")
+BLOCK_ORDER = ("enc1", "enc2", "enc3", "enc4", "bottleneck", "dec4", "dec3", "dec2", "dec1")
+WIDTHS = {"enc1": 64, "enc2": 128, "enc3": 256, "enc4": 512, "bottleneck": 1024,
+          "dec4": 512, "dec3": 256, "dec2": 128, "dec1": 64}
+
+
+def _stage_pair(cin, cout, d):
+    """Two (dilated 3x3 conv -> BatchNorm -> ReLU) stages with Sequential indices 0..5, so the
+    state-dict keys are ``<block>.{0,1,3,4}.*`` exactly as in the reference."""
+    mods = []
+    for c in (cin, cout):
+        mods += [nn.Conv2d(c, cout, kernel_size=3, padding=d, dilation=d),
+                 nn.BatchNorm2d(cout), nn.ReLU(inplace=True)]
+    return nn.Sequential(*mods)
+
+
+class _UNetFamily(nn.Module):
+    """Shared topology; subclasses only choose the per-block dilation."""
+
+    DILATIONS: dict = {}
+
+    def __init__(self, in_channels=3, out_channels=1):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        d = self.DILATIONS
+        prev = in_channels
+        for name in ENCODER + ("bottleneck",):           # registration order == reference order
+            setattr(self, name, _stage_pair(prev, WIDTHS[name], d[name]))
+            prev = WIDTHS[name]
+        for lvl in (4, 3, 2, 1):
+            w = WIDTHS[f"dec{lvl}"]
+            setattr(self, f"upconv{lvl}", nn.ConvTranspose2d(2 * w, w, kernel_size=2, stride=2))
+            setattr(self, f"dec{lvl}", _stage_pair(2 * w, w, d[f"dec{lvl}"]))
+        self.out_conv = nn.Conv2d(64, out_channels, kernel_size=1)
+        # compute configuration of the HIP path (not part of the reference surface):
+        #   "f32"  -- fp32 storage, exact-fp32 MFMA (parity configuration)
+        #   "bf16" -- bf16 activations/weights, fp32 accumulate (throughput configuration)
+        self.compute_dtype = "f32"
+        self._engine = None
+        self.grad_ready_hook = None      # set by the data-parallel wrapper (dp.py)
+
+    # ------------------------------------------------------------------ configuration
+    def set_compute_dtype(self, name):
+        if name not in ("f32", "bf16"):
+            raise ValueError(f"compute dtype must be 'f32' or 'bf16', got {name!r}")
+        self.compute_dtype = name
+        self._engine = None
+        return self
+
+    def dilation_of(self, block):
+        return self.DILATIONS[block]
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x):
+        if x.is_cuda:
+            from . import engine                       # raises if libunetdc_hip.so is missing
+            if self._engine is None or not self._engine.matches(x):
+                self._engine = engine.UNetEngine(self, x)
+            return self._engine.run(x)
+        return self._forward_aten_cpu(x)
+
+    def _forward_aten_cpu(self, x):
+        skips = []
+        h = x
+        for name in ENCODER:
+            h = getattr(self, name)(h)
+            skips.append(h)
+            h = F.max_pool2d(h, 2)
+        h = self.bottleneck(h)
+        for lvl in (4, 3, 2, 1):
+            up = getattr(self, f"upconv{lvl}")(h)
+            h = getattr(self, f"dec{lvl}")(torch.cat([up, skips[lvl - 1]], dim=1))
+        return torch.sigmoid(self.out_conv(h))
+
+
+class UNetDC(_UNetFamily):
+    """Dilated U-Net: encoder dilations 1/2/4/8, bottleneck 16, decoder 1 (model_2.py:10-30)."""
+    DILATIONS = {"enc1": 1, "enc2": 2, "enc3": 4, "enc4": 8, "bottleneck": 16,
+                 "dec4": 1, "dec3": 1, "dec2": 1, "dec1": 1}
+
+
+class UNet(_UNetFamily):
+    """Plain U-Net: every dilation 1 (models/model.py:25-33)."""
+    DILATIONS = {b: 1 for b in BLOCK_ORDER}

@@ -1,0 +1,72 @@
+"""Host-side losses and metrics -- same names and semantics as the reference's
+``utils/metrics_DC.py`` (north_star keeps the Focal/Dice loss in PyTorch on the host side).
+
+The autograd of :func:`focal_dice_loss` produces dL/dprobs, which is the input of the HIP
+backward pass (head backward kernel).  Reference lines: dice_loss :11-17, combined_loss :19-22,
+dice_coef :24-29, FocalLoss :31-63, focal_dice_loss :65-73, calculate_metrics :75-85.
+The seaborn confusion-matrix plot (:87-116) is reporting-only and out of scope.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _per_map_dice(a, b, smooth):
+    inter = (a * b).sum(dim=(2, 3))
+    total = a.sum(dim=(2, 3)) + b.sum(dim=(2, 3))
+    return (2.0 * inter + smooth) / (total + smooth)
+
+
+def dice_loss(pred, target, smooth=1e-7):
+    """1 - mean over (n, c) of the soft Dice coefficient computed over (H, W)."""
+    return 1 - _per_map_dice(pred.contiguous(), target.contiguous(), smooth).mean()
+
+
+def combined_loss(pred, target):
+    """0.5 * BCE + 0.5 * Dice (the plain-UNet criterion of train.py)."""
+    return 0.5 * F.binary_cross_entropy(pred, target) + 0.5 * dice_loss(pred, target)
+
+
+def dice_coef(y_true, y_pred, smooth=1e-7):
+    """Hard Dice: predictions are binarised at 0.5 first (a no-op on an already binary mask)."""
+    return _per_map_dice(y_true, (y_pred > 0.5).float(), smooth).mean()
+
+
+class FocalLoss(nn.Module):
+    """Binary focal loss on probabilities: alpha * (1 - pt)^gamma * bce with pt = exp(-bce)."""
+
+    def __init__(self, alpha=1.0, gamma=2.0, reduction="mean"):
+        super().__init__()
+        self.alpha, self.gamma, self.reduction = alpha, gamma, reduction
+
+    def forward(self, inputs, targets):
+        bce = F.binary_cross_entropy(inputs, targets, reduction="none")
+        pt = torch.exp(-bce)
+        loss = self.alpha * (1 - pt) ** self.gamma * bce
+        if self.reduction == "mean":
+            return loss.mean()
+        if self.reduction == "sum":
+            return loss.sum()
+        return loss
+
+
+def focal_dice_loss(pred, target, alpha=1.0, gamma=2.0, ratio=0.3):
+    """ratio * focal + (1 - ratio) * dice; train_DC_focal.py:222 uses (1.0, 2.0, 0.3)."""
+    fl = FocalLoss(alpha=alpha, gamma=gamma, reduction="mean")(pred, target)
+    return ratio * fl + (1 - ratio) * dice_loss(pred, target)
+
+
+def calculate_metrics(y_true, y_pred):
+    """precision / recall / F1 / specificity of the 0.3-thresholded prediction (zero_division=1)."""
+    yp = (y_pred > 0.3).reshape(-1).cpu().numpy().astype(bool)
+    yt = (y_true.reshape(-1).cpu().numpy() > 0.5)
+    tp = float(np.sum(yp & yt)); fp = float(np.sum(yp & ~yt))
+    fn = float(np.sum(~yp & yt)); tn = float(np.sum(~yp & ~yt))
+    precision = tp / (tp + fp) if tp + fp > 0 else 1.0
+    recall = tp / (tp + fn) if tp + fn > 0 else 1.0
+    f1 = 2 * precision * recall / (precision + recall) if precision + recall > 0 else 0.0
+    specificity = tn / (tn + fp) if tn + fp > 0 else 0.0
+    return precision, recall, f1, specificity
