@@ -1,0 +1,140 @@
+/* libunetdc_hip.so -- C ABI of the MI355X (gfx950) U-Net / U-Net-DC forward+backward kernels.
+ *
+ * This is the drop-in boundary for the hot path of malani86/unet-DC-segmentation.  The reference
+ * has no FFI of its own: its boundary is the nn.Module contract of UNetDC / UNet plus autograd
+ * (SURVEY.md section 8b), and every operator below replaces the ATen call the reference makes at
+ * the cited line of /root/reference.  Conventions:
+ *
+ *   - plain C: raw DEVICE pointers, explicit sizes/strides, a hipStream_t passed as void*;
+ *     no torch types, no C++ exceptions.  Every function returns 0 on success, a negative
+ *     UNETDC_E* code otherwise; unetdc_last_error() returns a thread-local message.
+ *   - the library never allocates or frees device memory: activations, packed weights and
+ *     workspaces are owned by the caller (PyTorch's caching allocator in the Python host layer).
+ *   - activations are NHWC ("pixel-major") in the compute type `dtype` (UNETDC_F32 / UNETDC_BF16):
+ *     element (n,y,x,c) at ((n*H + y)*W + x)*ld + c.  `ld` (in elements, multiple of 16 bytes)
+ *     lets a tensor be a channel slice of a wider buffer, which is how torch.cat
+ *     (models/model_2.py:68,71,74,77) costs zero bytes: the up-convolution writes channels
+ *     [0,C) and the encoder skip writes channels [C,2C) of one [pixels][2C] buffer.
+ *   - the network input (NCHW fp32, train_DC_focal.py:250) and output (NCHW fp32 probabilities,
+ *     model_2.py:80) keep the reference's layout; parameters and their gradients are fp32 in
+ *     PyTorch layout (Conv2d [Cout][Cin][3][3], ConvTranspose2d [Cin][Cout][2][2]).
+ *   - kernels are enqueued on the given stream and are re-entrant; reductions are two-stage with
+ *     a fixed order (no float atomics), so results are bitwise reproducible.
+ */
+#ifndef UNETDC_HIP_H
+#define UNETDC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNETDC_ABI_VERSION 1
+
+#define UNETDC_F32 0
+#define UNETDC_BF16 1
+
+#define UNETDC_OK 0
+#define UNETDC_EINVAL (-1)      /* bad argument (shape, alignment, null pointer) */
+#define UNETDC_ELAUNCH (-2)     /* HIP reported an error for a launch */
+#define UNETDC_EWORKSPACE (-3)  /* caller-provided workspace too small */
+
+typedef void* unetdc_stream_t; /* hipStream_t */
+
+int unetdc_version(void);
+const char* unetdc_last_error(void);
+
+/* ---- weight packing (derived caches of the fp32 parameters; redo after optimizer.step()) ------
+ * conv3x3:  w [Cout][Cin][3][3] -> w_fwd [9][Cout][Cin], w_dgrad [9][Cin][Cout] (taps flipped)
+ * convT2x2: w [Cin][Cout][2][2] -> w_fwd [4*Cout][Cin] (row (a*2+b)*Cout+co), w_dgrad [4][Cin][Cout]
+ * w_dgrad may be NULL (inference). */
+int unetdc_pack_conv3x3(const float* w, void* w_fwd, void* w_dgrad, int cout, int cin, int dtype, unetdc_stream_t s);
+int unetdc_pack_convT2x2(const float* w, void* w_fwd, void* w_dgrad, int cin, int cout, int dtype, unetdc_stream_t s);
+
+/* ---- dilated 3x3 convolution, padding = dilation: nn.Conv2d at models/model_2.py:41-44,48-51 ---
+ * y = conv(x) + bias                                  (scale == NULL; training: raw pre-BN output)
+ * y = relu(conv(x)*scale + shift)                     (scale != NULL; eval: BN folded, bias inside shift)
+ * stats_part (nullable, training): per-block partial [rows][2][Cout] sums / sums of squares of y
+ * as stored, rows = unetdc_conv3x3_stats_rows(); the buffer must hold rows+64 rows.
+ * Cin must be a multiple of 64 (bf16) / 32 (fp32) and Cout of 64: every layer but enc1.0. */
+int unetdc_conv3x3_stats_rows(int64_t npixels, int cout);
+int unetdc_conv3x3_fwd(const void* x, int ldx, const void* w_fwd, const float* bias, const float* scale,
+                       const float* shift, void* y, int ldy, float* stats_part, int n, int h, int w, int cin,
+                       int cout, int dilation, int dtype, unetdc_stream_t s);
+/* dx = conv_transpose(dy): autograd of the above w.r.t. its input (dx has cin channels). */
+int unetdc_conv3x3_dgrad(const void* dy, int lddy, const void* w_dgrad, void* dx, int lddx, int n, int h, int w,
+                         int cin, int cout, int dilation, int dtype, unetdc_stream_t s);
+/* dw [Cout][Cin][3][3] fp32 = sum over pixels; workspace >= unetdc_conv3x3_wgrad_workspace() bytes. */
+int64_t unetdc_conv3x3_wgrad_workspace(int n, int h, int w, int cin, int cout, int dtype);
+int unetdc_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
+                         int64_t workspace_bytes, int n, int h, int w, int cin, int cout, int dilation, int dtype,
+                         unetdc_stream_t s);
+
+/* ---- first encoder convolution (small Cin, reads the NCHW fp32 image): model_2.py:10 (enc1.0) ---
+ * w is the fp32 PyTorch-layout parameter itself.  Same scale/shift/stats semantics as above. */
+int unetdc_conv3x3_first_stats_rows(int64_t npixels, int cout);
+int unetdc_conv3x3_first_fwd(const float* x_nchw, const float* w, const float* bias, const float* scale,
+                             const float* shift, void* y, int ldy, float* stats_part, int n, int h, int wd, int cin,
+                             int cout, int dilation, int dtype, unetdc_stream_t s);
+int64_t unetdc_conv3x3_first_wgrad_workspace(int n, int h, int w, int cin, int cout);
+int unetdc_conv3x3_first_wgrad(const float* x_nchw, const void* dy, int lddy, float* dw, void* workspace,
+                               int64_t workspace_bytes, int n, int h, int w, int cin, int cout, int dilation,
+                               int dtype, unetdc_stream_t s);
+
+/* ---- ConvTranspose2d(k=2, s=2): models/model_2.py:20,23,26,29 and :67,70,73,76 -----------------
+ * fwd: x [n,h,w,cin] -> up [n,2h,2w,cout] (+bias) written with pixel stride ldup (concat slice). */
+int unetdc_convT2x2_fwd(const void* x, int ldx, const void* w_fwd, const float* bias, void* up, int ldup, int n,
+                        int h, int w, int cin, int cout, int dtype, unetdc_stream_t s);
+int unetdc_convT2x2_dgrad(const void* dup, int lddup, const void* w_dgrad, void* dx, int lddx, int n, int h, int w,
+                          int cin, int cout, int dtype, unetdc_stream_t s);
+int64_t unetdc_convT2x2_wgrad_workspace(int n, int h, int w, int cin, int cout, int dtype);
+/* dw [Cin][Cout][2][2] fp32 (the bias gradient is unetdc_channel_sum of dup). */
+int unetdc_convT2x2_wgrad(const void* x, int ldx, const void* dup, int lddup, float* dw, void* workspace,
+                          int64_t workspace_bytes, int n, int h, int w, int cin, int cout, int dtype,
+                          unetdc_stream_t s);
+
+/* ---- BatchNorm2d + ReLU (+ max_pool2d): models/model_2.py:45-46,52-53 and :59-61,64 -------------
+ * bn_finalize: batch statistics from the conv's partials -> scale = gamma*rstd,
+ *   shift = beta - mean*scale, saved mean/rstd; running stats updated with momentum (unbiased var)
+ *   when running_mean != NULL. `count` = n*h*w. */
+int unetdc_bn_finalize(const float* stats_part, int rows, int64_t count, const float* gamma, const float* beta,
+                       float eps, float momentum, float* running_mean, float* running_var, float* scale,
+                       float* shift, float* mean, float* rstd, int c, unetdc_stream_t s);
+/* eval: scale = gamma/sqrt(running_var+eps), shift = beta + (conv_bias - running_mean)*scale */
+int unetdc_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                          const float* running_var, const float* conv_bias, float eps, float* scale, float* shift,
+                          int c, unetdc_stream_t s);
+/* a = relu(scale*y + shift) (a = y when scale == NULL); pooled (nullable) = max_pool2d(a, 2).
+ * `a` may be NULL when only the pooled tensor is wanted and scale == NULL. */
+int unetdc_bn_relu_apply(const void* y, int ldy, const float* scale, const float* shift, void* a, int lda,
+                         void* pooled, int ldp, int n, int h, int w, int c, int dtype, unetdc_stream_t s);
+/* backward of conv-output y -> BN(train) -> ReLU (-> skip and/or 2x2 max-pool consumers):
+ *   incoming gradient = dskip (nullable, full resolution) + scatter(dpool) (nullable, half
+ *   resolution, routed to the window arg-max recomputed from y); outputs dy (gradient of the conv
+ *   output), dgamma, dbeta and the conv-bias gradient dbias (nullable). */
+int64_t unetdc_bn_relu_bwd_workspace(int n, int h, int w, int c, int pooled, int dtype);
+int unetdc_bn_relu_bwd(const void* dskip, int ldskip, const void* dpool, int ldpool, const void* y, int ldy,
+                       const float* scale, const float* shift, const float* mean, const float* rstd,
+                       const float* gamma, void* dy, int lddy, float* dgamma, float* dbeta, float* dbias,
+                       void* workspace, int64_t workspace_bytes, int n, int h, int w, int c, int dtype,
+                       unetdc_stream_t s);
+
+/* ---- head: Conv2d(C, OC, 1) + sigmoid, models/model_2.py:32,79-80 ------------------------------
+ * w [OC][C] fp32, probs/dprobs NCHW fp32 [n][OC][h][w]. */
+int unetdc_head_fwd(const void* a, int lda, const float* w, const float* b, float* probs, int n, int h, int wd,
+                    int c, int oc, int dtype, unetdc_stream_t s);
+int64_t unetdc_head_bwd_workspace(int n, int h, int w, int c, int oc, int dtype);
+int unetdc_head_bwd(const float* dprobs, const float* probs, const void* a, int lda, const float* w, void* da,
+                    int ldda, float* dw, float* db, void* workspace, int64_t workspace_bytes, int n, int h, int wd,
+                    int c, int oc, int dtype, unetdc_stream_t s);
+
+/* ---- per-channel column sum of an NHWC tensor (ConvTranspose2d bias gradient) ------------------ */
+int64_t unetdc_channel_sum_workspace(int64_t npixels, int c);
+int unetdc_channel_sum(const void* x, int ldx, float* out, void* workspace, int64_t workspace_bytes,
+                       int64_t npixels, int c, int dtype, unetdc_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNETDC_HIP_H */

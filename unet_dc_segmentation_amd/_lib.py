@@ -1,0 +1,86 @@
+"""ctypes binding of ``libunetdc_hip.so`` (C ABI declared in ``include/unetdc_hip.h``).
+
+The library is loaded AFTER ``import torch`` so that its ``libamdhip64.so.7`` dependency resolves
+to the HIP runtime PyTorch-ROCm already has in the process (same SONAME): kernels are then
+enqueued on PyTorch's own streams.  There is no fallback: if the shared object is missing or a
+symbol is absent, importing/using the HIP path raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+import torch  # noqa: F401  (must be imported before the CDLL below -- see module docstring)
+
+F32, BF16 = 0, 1
+LIB_NAME = "libunetdc_hip.so"
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+P, I, L, F = c_void_p, c_int, c_int64, c_float
+
+# name -> (restype, argtypes); mirrors include/unetdc_hip.h one to one
+SIGNATURES = {
+    "unetdc_version": (I, []),
+    "unetdc_last_error": (c_char_p, []),
+    "unetdc_pack_conv3x3": (I, [P, P, P, I, I, I, P]),
+    "unetdc_pack_convT2x2": (I, [P, P, P, I, I, I, P]),
+    "unetdc_conv3x3_stats_rows": (I, [L, I]),
+    "unetdc_conv3x3_fwd": (I, [P, I, P, P, P, P, P, I, P, I, I, I, I, I, I, I, P]),
+    "unetdc_conv3x3_dgrad": (I, [P, I, P, P, I, I, I, I, I, I, I, I, P]),
+    "unetdc_conv3x3_wgrad_workspace": (L, [I, I, I, I, I, I]),
+    "unetdc_conv3x3_wgrad": (I, [P, I, P, I, P, P, L, I, I, I, I, I, I, I, P]),
+    "unetdc_conv3x3_first_stats_rows": (I, [L, I]),
+    "unetdc_conv3x3_first_fwd": (I, [P, P, P, P, P, P, I, P, I, I, I, I, I, I, I, P]),
+    "unetdc_conv3x3_first_wgrad_workspace": (L, [I, I, I, I, I]),
+    "unetdc_conv3x3_first_wgrad": (I, [P, P, I, P, P, L, I, I, I, I, I, I, I, P]),
+    "unetdc_convT2x2_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, I, P]),
+    "unetdc_convT2x2_dgrad": (I, [P, I, P, P, I, I, I, I, I, I, I, P]),
+    "unetdc_convT2x2_wgrad_workspace": (L, [I, I, I, I, I, I]),
+    "unetdc_convT2x2_wgrad": (I, [P, I, P, I, P, P, L, I, I, I, I, I, I, P]),
+    "unetdc_bn_finalize": (I, [P, I, L, P, P, F, F, P, P, P, P, P, P, I, P]),
+    "unetdc_bn_eval_affine": (I, [P, P, P, P, P, F, P, P, I, P]),
+    "unetdc_bn_relu_apply": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, P]),
+    "unetdc_bn_relu_bwd_workspace": (L, [I, I, I, I, I, I]),
+    "unetdc_bn_relu_bwd": (I, [P, I, P, I, P, I, P, P, P, P, P, P, I, P, P, P, P, L, I, I, I, I, I, P]),
+    "unetdc_head_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, P]),
+    "unetdc_head_bwd_workspace": (L, [I, I, I, I, I, I]),
+    "unetdc_head_bwd": (I, [P, P, P, I, P, P, I, P, P, P, L, I, I, I, I, I, I, P]),
+    "unetdc_channel_sum_workspace": (L, [L, I]),
+    "unetdc_channel_sum": (I, [P, I, P, P, L, L, I, I, P]),
+}
+
+_lib = None
+
+
+class UnetdcError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the HIP library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UnetdcError(
+            f"{LIB_PATH} not found: the MI355X HIP library has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU/PyTorch "
+            "fallback for tensors on a HIP device.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().unetdc_last_error().decode(errors="replace")
+        raise UnetdcError(f"{what or 'unetdc'} failed (code {rc}): {msg}")
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,46 @@
+"""Build ``libunetdc_hip.so`` in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SOURCES = ["abi.hip", "igemm_conv.hip", "wgrad.hip", "first_conv.hip", "elementwise.hip"]
+HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "unetdc_hip.h")]
+OUT = os.path.join(HERE, "libunetdc_hip.so")
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (ROCm toolchain required to build the gfx950 kernels)")
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return OUT
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+           "-Wno-unused-function", *[os.path.join(CSRC, f) for f in SOURCES], "-o", OUT]
+    if verbose:
+        print("[unetdc build]", " ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("hipcc failed building libunetdc_hip.so")
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

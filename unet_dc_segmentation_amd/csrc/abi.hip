@@ -1,0 +1,235 @@
+// extern "C" entry points of libunetdc_hip.so (declared in include/unetdc_hip.h).
+// Thin argument validation + geometry setup; the kernels live in the other translation units.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/unetdc_hip.h"
+#include "kernels.h"
+
+namespace unetdc {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return UNETDC_ELAUNCH;
+  }
+  return UNETDC_OK;
+}
+
+static void taps3x3(int d, int* offy, int* offx) {
+  for (int t = 0; t < 9; ++t) {
+    offy[t] = (t / 3 - 1) * d;
+    offx[t] = (t % 3 - 1) * d;
+  }
+}
+
+}  // namespace unetdc
+
+using namespace unetdc;
+
+#define GEOM_CHECK(n, h, w)                                                                          \
+  UNETDC_REQUIRE((n) > 0 && (h) > 0 && (w) > 0, "bad geometry n=%d h=%d w=%d", (int)(n), (int)(h), (int)(w))
+
+extern "C" {
+
+int unetdc_version(void) { return UNETDC_ABI_VERSION; }
+const char* unetdc_last_error(void) { return g_err; }
+
+int unetdc_pack_conv3x3(const float* w, void* w_fwd, void* w_dgrad, int cout, int cin, int dtype, unetdc_stream_t s) {
+  return launch_pack_conv3x3(w, w_fwd, w_dgrad, cout, cin, dtype, (hipStream_t)s);
+}
+int unetdc_pack_convT2x2(const float* w, void* w_fwd, void* w_dgrad, int cin, int cout, int dtype, unetdc_stream_t s) {
+  return launch_pack_convT2x2(w, w_fwd, w_dgrad, cin, cout, dtype, (hipStream_t)s);
+}
+
+int unetdc_conv3x3_stats_rows(int64_t npixels, int cout) { return igemm_mblocks((long)npixels, cout); }
+
+int unetdc_conv3x3_fwd(const void* x, int ldx, const void* w_fwd, const float* bias, const float* scale,
+                       const float* shift, void* y, int ldy, float* stats_part, int n, int h, int w, int cin,
+                       int cout, int dilation, int dtype, unetdc_stream_t s) {
+  GEOM_CHECK(n, h, w);
+  UNETDC_REQUIRE(dilation >= 1, "conv3x3_fwd: dilation must be >= 1");
+  UNETDC_REQUIRE(ldx >= cin && ldy >= cout, "conv3x3_fwd: ld smaller than channel count");
+  IgemmParams p{};
+  p.x = x; p.w = w_fwd; p.out = y; p.bias = bias; p.scale = scale; p.shift = shift; p.stats = stats_part;
+  p.M = n * h * w; p.Ho = h; p.Wo = w; p.Hi = h; p.Wi = w; p.Cin = cin; p.Cout = cout; p.ldx = ldx; p.ldo = ldy;
+  p.ntaps = 9; p.stride = 1;
+  p.mode = scale ? MODE_AFFINE_RELU : (stats_part ? MODE_STATS : MODE_STORE);
+  taps3x3(dilation, p.offy, p.offx);
+  return launch_igemm(p, dtype, (hipStream_t)s);
+}
+
+int unetdc_conv3x3_dgrad(const void* dy, int lddy, const void* w_dgrad, void* dx, int lddx, int n, int h, int w,
+                         int cin, int cout, int dilation, int dtype, unetdc_stream_t s) {
+  GEOM_CHECK(n, h, w);
+  UNETDC_REQUIRE(dilation >= 1, "conv3x3_dgrad: dilation must be >= 1");
+  UNETDC_REQUIRE(lddy >= cout && lddx >= cin, "conv3x3_dgrad: ld smaller than channel count");
+  IgemmParams p{};
+  p.x = dy; p.w = w_dgrad; p.out = dx;
+  p.M = n * h * w; p.Ho = h; p.Wo = w; p.Hi = h; p.Wi = w; p.Cin = cout; p.Cout = cin; p.ldx = lddy; p.ldo = lddx;
+  p.ntaps = 9; p.stride = 1; p.mode = MODE_STORE;
+  taps3x3(dilation, p.offy, p.offx);
+  return launch_igemm(p, dtype, (hipStream_t)s);
+}
+
+int64_t unetdc_conv3x3_wgrad_workspace(int n, int h, int w, int cin, int cout, int dtype) {
+  return wgrad_workspace_bytes((long)n * h * w, cout, cin, 9, dtype);
+}
+
+int unetdc_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,
+                         int64_t workspace_bytes, int n, int h, int w, int cin, int cout, int dilation, int dtype,
+                         unetdc_stream_t s) {
+  GEOM_CHECK(n, h, w);
+  UNETDC_REQUIRE(dilation >= 1, "conv3x3_wgrad: dilation must be >= 1");
+  WgradParams p{};
+  p.a = dy; p.b = x; p.N = n; p.H = h; p.W = w; p.Hb = h; p.Wb = w; p.CI = cout; p.CJ = cin;
+  p.lda = lddy; p.ldb = ldx; p.ntaps = 9; p.stride = 1;
+  taps3x3(dilation, p.offy, p.offx);
+  return launch_wgrad(p, dw, workspace, (long)workspace_bytes, dtype, (hipStream_t)s);
+}
+
+int unetdc_conv3x3_first_stats_rows(int64_t npixels, int cout) { return first_conv_mblocks((long)npixels, cout); }
+
+int unetdc_conv3x3_first_fwd(const float* x_nchw, const float* w, const float* bias, const float* scale,
+                             const float* shift, void* y, int ldy, float* stats_part, int n, int h, int wd, int cin,
+                             int cout, int dilation, int dtype, unetdc_stream_t s) {
+  GEOM_CHECK(n, h, wd);
+  UNETDC_REQUIRE(dilation >= 1 && ldy >= cout, "conv3x3_first_fwd: bad dilation/ld");
+  UNETDC_REQUIRE((scale == nullptr) == (shift == nullptr), "conv3x3_first_fwd: scale/shift mismatch");
+  FirstParams p{};
+  p.x = x_nchw; p.w = w; p.bias = bias; p.scale = scale; p.shift = shift; p.y = y; p.stats = stats_part;
+  p.N = n; p.H = h; p.W = wd; p.Cin = cin; p.Cout = cout; p.ldy = ldy; p.dil = dilation;
+  return launch_first_fwd(p, dtype, (hipStream_t)s);
+}
+
+int64_t unetdc_conv3x3_first_wgrad_workspace(int n, int h, int w, int cin, int cout) {
+  return first_wgrad_workspace_bytes((long)n * h * w, cin, cout);
+}
+
+int unetdc_conv3x3_first_wgrad(const float* x_nchw, const void* dy, int lddy, float* dw, void* workspace,
+                               int64_t workspace_bytes, int n, int h, int w, int cin, int cout, int dilation,
+                               int dtype, unetdc_stream_t s) {
+  GEOM_CHECK(n, h, w);
+  FirstWgradParams p{};
+  p.x = x_nchw; p.dy = dy; p.N = n; p.H = h; p.W = w; p.Cin = cin; p.Cout = cout; p.lddy = lddy; p.dil = dilation;
+  return launch_first_wgrad(p, dw, workspace, (long)workspace_bytes, dtype, (hipStream_t)s);
+}
+
+int unetdc_convT2x2_fwd(const void* x, int ldx, const void* w_fwd, const float* bias, void* up, int ldup, int n,
+                        int h, int w, int cin, int cout, int dtype, unetdc_stream_t s) {
+  GEOM_CHECK(n, h, w);
+  UNETDC_REQUIRE(ldx >= cin && ldup >= cout, "convT2x2_fwd: ld smaller than channel count");
+  IgemmParams p{};
+  p.x = x; p.w = w_fwd; p.out = up; p.bias = bias;
+  p.M = n * h * w; p.Ho = h; p.Wo = w; p.Hi = h; p.Wi = w; p.Cin = cin; p.Cout = 4 * cout; p.ldx = ldx; p.ldo = ldup;
+  p.ntaps = 1; p.stride = 1; p.mode = MODE_SHUFFLE; p.shuf_c = cout;
+  p.offy[0] = 0; p.offx[0] = 0;
+  return launch_igemm(p, dtype, (hipStream_t)s);
+}
+
+int unetdc_convT2x2_dgrad(const void* dup, int lddup, const void* w_dgrad, void* dx, int lddx, int n, int h, int w,
+                          int cin, int cout, int dtype, unetdc_stream_t s) {
+  GEOM_CHECK(n, h, w);
+  UNETDC_REQUIRE(lddup >= cout && lddx >= cin, "convT2x2_dgrad: ld smaller than channel count");
+  IgemmParams p{};
+  p.x = dup; p.w = w_dgrad; p.out = dx;
+  p.M = n * h * w; p.Ho = h; p.Wo = w; p.Hi = 2 * h; p.Wi = 2 * w; p.Cin = cout; p.Cout = cin; p.ldx = lddup;
+  p.ldo = lddx; p.ntaps = 4; p.stride = 2; p.mode = MODE_STORE;
+  for (int t = 0; t < 4; ++t) { p.offy[t] = t >> 1; p.offx[t] = t & 1; }
+  return launch_igemm(p, dtype, (hipStream_t)s);
+}
+
+int64_t unetdc_convT2x2_wgrad_workspace(int n, int h, int w, int cin, int cout, int dtype) {
+  return wgrad_workspace_bytes((long)n * h * w, cin, cout, 4, dtype);
+}
+
+int unetdc_convT2x2_wgrad(const void* x, int ldx, const void* dup, int lddup, float* dw, void* workspace,
+                          int64_t workspace_bytes, int n, int h, int w, int cin, int cout, int dtype,
+                          unetdc_stream_t s) {
+  GEOM_CHECK(n, h, w);
+  WgradParams p{};
+  p.a = x; p.b = dup; p.N = n; p.H = h; p.W = w; p.Hb = 2 * h; p.Wb = 2 * w; p.CI = cin; p.CJ = cout;
+  p.lda = ldx; p.ldb = lddup; p.ntaps = 4; p.stride = 2;
+  for (int t = 0; t < 4; ++t) { p.offy[t] = t >> 1; p.offx[t] = t & 1; }
+  return launch_wgrad(p, dw, workspace, (long)workspace_bytes, dtype, (hipStream_t)s);
+}
+
+int unetdc_bn_finalize(const float* stats_part, int rows, int64_t count, const float* gamma, const float* beta,
+                       float eps, float momentum, float* running_mean, float* running_var, float* scale,
+                       float* shift, float* mean, float* rstd, int c, unetdc_stream_t s) {
+  return launch_bn_finalize(stats_part, rows, (long)count, gamma, beta, eps, momentum, running_mean, running_var,
+                            scale, shift, mean, rstd, c, (hipStream_t)s);
+}
+
+int unetdc_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                          const float* running_var, const float* conv_bias, float eps, float* scale, float* shift,
+                          int c, unetdc_stream_t s) {
+  return launch_bn_eval_affine(gamma, beta, running_mean, running_var, conv_bias, eps, scale, shift, c,
+                               (hipStream_t)s);
+}
+
+int unetdc_bn_relu_apply(const void* y, int ldy, const float* scale, const float* shift, void* a, int lda,
+                         void* pooled, int ldp, int n, int h, int w, int c, int dtype, unetdc_stream_t s) {
+  GEOM_CHECK(n, h, w);
+  ApplyParams p{};
+  p.y = y; p.a = a; p.pooled = pooled; p.scale = scale; p.shift = shift;
+  p.N = n; p.H = h; p.W = w; p.C = c; p.ldy = ldy; p.lda = lda; p.ldp = ldp;
+  return launch_apply(p, dtype, (hipStream_t)s);
+}
+
+int64_t unetdc_bn_relu_bwd_workspace(int n, int h, int w, int c, int pooled, int dtype) {
+  return bn_bwd_workspace_bytes(n, h, w, c, pooled, dtype);
+}
+
+int unetdc_bn_relu_bwd(const void* dskip, int ldskip, const void* dpool, int ldpool, const void* y, int ldy,
+                       const float* scale, const float* shift, const float* mean, const float* rstd,
+                       const float* gamma, void* dy, int lddy, float* dgamma, float* dbeta, float* dbias,
+                       void* workspace, int64_t workspace_bytes, int n, int h, int w, int c, int dtype,
+                       unetdc_stream_t s) {
+  GEOM_CHECK(n, h, w);
+  BnBwdParams p{};
+  p.dskip = dskip; p.dpool = dpool; p.y = y; p.dy = dy; p.scale = scale; p.shift = shift; p.mean = mean; p.rstd = rstd;
+  p.N = n; p.H = h; p.W = w; p.C = c; p.lds = ldskip; p.ldp = ldpool; p.ldy = ldy; p.lddy = lddy;
+  return launch_bn_bwd(p, gamma, dgamma, dbeta, dbias, workspace, (long)workspace_bytes, dtype, (hipStream_t)s);
+}
+
+int unetdc_head_fwd(const void* a, int lda, const float* w, const float* b, float* probs, int n, int h, int wd,
+                    int c, int oc, int dtype, unetdc_stream_t s) {
+  GEOM_CHECK(n, h, wd);
+  HeadParams p{};
+  p.a = a; p.w = w; p.b = b; p.probs = probs; p.N = n; p.H = h; p.W = wd; p.C = c; p.OC = oc; p.lda = lda;
+  return launch_head_fwd(p, dtype, (hipStream_t)s);
+}
+
+int64_t unetdc_head_bwd_workspace(int n, int h, int w, int c, int oc, int dtype) {
+  return head_bwd_workspace_bytes(n, h, w, c, oc, dtype);
+}
+
+int unetdc_head_bwd(const float* dprobs, const float* probs, const void* a, int lda, const float* w, void* da,
+                    int ldda, float* dw, float* db, void* workspace, int64_t workspace_bytes, int n, int h, int wd,
+                    int c, int oc, int dtype, unetdc_stream_t s) {
+  GEOM_CHECK(n, h, wd);
+  HeadParams p{};
+  p.a = a; p.w = w; p.probs = const_cast<float*>(probs); p.dprobs = dprobs; p.da = da;
+  p.N = n; p.H = h; p.W = wd; p.C = c; p.OC = oc; p.lda = lda; p.ldda = ldda;
+  return launch_head_bwd(p, dw, db, workspace, (long)workspace_bytes, dtype, (hipStream_t)s);
+}
+
+int64_t unetdc_channel_sum_workspace(int64_t npixels, int c) { return channel_sum_workspace_bytes((long)npixels, c); }
+
+int unetdc_channel_sum(const void* x, int ldx, float* out, void* workspace, int64_t workspace_bytes,
+                       int64_t npixels, int c, int dtype, unetdc_stream_t s) {
+  return launch_channel_sum(x, ldx, out, workspace, (long)workspace_bytes, (long)npixels, c, dtype, (hipStream_t)s);
+}
+
+}  // extern "C"

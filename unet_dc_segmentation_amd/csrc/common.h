@@ -1,0 +1,115 @@
+// Shared device/host helpers for the gfx950 (CDNA4, wave64) U-Net kernels.
+// All activation tensors are NHWC ("pixel-major"): element (n, y, x, c) lives at
+// ((n*H + y)*W + x) * ld + c, where ld >= C lets a tensor be a channel slice of a wider
+// buffer (the decoder's zero-copy concat buffers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define UNETDC_F32 0
+#define UNETDC_BF16 1
+
+#define UNETDC_OK 0
+#define UNETDC_EINVAL (-1)
+#define UNETDC_ELAUNCH (-2)
+#define UNETDC_EWORKSPACE (-3)
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+namespace unetdc {
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define UNETDC_REQUIRE(cond, ...)                     \
+  do {                                                \
+    if (!(cond)) {                                    \
+      unetdc::set_error(__VA_ARGS__);                 \
+      return UNETDC_EINVAL;                           \
+    }                                                 \
+  } while (0)
+
+// ---- element traits: 16-byte chunks -----------------------------------------------------------
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int PER_CHUNK = 4;   // elements per 16-byte chunk
+  static constexpr int BYTES = 4;
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int PER_CHUNK = 8;
+  static constexpr int BYTES = 2;
+};
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// round a float through the storage type (what a later kernel will read back)
+template <typename T> __device__ __forceinline__ float round_through(float v) { return to_f32(from_f32<T>(v)); }
+
+// A 16-byte chunk viewed as N elements of T, converted to/from fp32.
+template <typename T> struct Chunk;
+template <> struct Chunk<float> {
+  static constexpr int N = 4;
+  __device__ static void unpack(const u32x4& c, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = __builtin_bit_cast(float, c[i]);
+  }
+  __device__ static u32x4 pack(const float* f) {
+    u32x4 c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = __builtin_bit_cast(unsigned int, f[i]);
+    return c;
+  }
+};
+template <> struct Chunk<bf16_t> {
+  static constexpr int N = 8;
+  __device__ static void unpack(const u32x4& c, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __builtin_bit_cast(float, c[i] << 16);
+      f[2 * i + 1] = __builtin_bit_cast(float, c[i] & 0xffff0000u);
+    }
+  }
+  __device__ static u32x4 pack(const float* f) {
+    u32x4 c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bf16_t lo = (bf16_t)f[2 * i], hi = (bf16_t)f[2 * i + 1];
+      c[i] = (unsigned int)__builtin_bit_cast(unsigned short, lo) |
+             ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
+    }
+    return c;
+  }
+};
+
+__device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+// XCD-aware remap of a linear workgroup id: blocks b and b+8 share an XCD (observed round-robin
+// placement; speed only, never correctness), so give each XCD one contiguous chunk of the tile
+// list to keep neighbouring tiles in one L2.  Bijective for any nwg.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + local;
+}
+
+// wave-level sum over the 64 lanes
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace unetdc

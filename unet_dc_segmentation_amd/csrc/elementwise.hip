@@ -1,0 +1,705 @@
+// HBM-bound kernels of the U-Net path: BatchNorm statistics/normalisation (+ReLU, +2x2 max-pool),
+// their backward (with the pool scatter and skip-gradient sum folded in), the 1x1 sigmoid head,
+// and weight re-packing.  All tensors NHWC, every global access is a 16-byte chunk; reductions
+// are two-stage with fixed summation order (no float atomics -> bitwise reproducible).
+#include "kernels.h"
+
+namespace unetdc {
+
+// ================================================================================================
+// column sums of a [nrows][L] fp32 matrix into R row groups: out[r][l] = sum_{i in group r} in[i][l]
+// ================================================================================================
+__global__ __launch_bounds__(256) void colsum_stage_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           int nrows, int L, int rows_per_group) {
+  __shared__ float red[8][33];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + cl, grp = blockIdx.y;
+  const int rbeg = grp * rows_per_group;
+  const int rend = min(rbeg + rows_per_group, nrows);
+  float s = 0.f;
+  if (col < L)
+    for (int i = rbeg + rl; i < rend; i += 8) s += in[(long)i * L + col];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && col < L) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += red[q][cl];
+    out[(long)grp * L + col] = t;
+  }
+}
+
+// Reduce `nparts` rows to at most 64 rows written at parts + nparts*L (caller provides 64 spare rows).
+// Returns pointer/rows of the reduced set through the out-params.
+int reduce_parts(const float* parts, int nparts, int L, const float** red_ptr, int* red_rows, hipStream_t stream) {
+  if (nparts <= 64) {
+    *red_ptr = parts;
+    *red_rows = nparts;
+    return UNETDC_OK;
+  }
+  float* out = const_cast<float*>(parts) + (long)nparts * L;
+  const int rpg = (nparts + 63) / 64;
+  const int groups = (nparts + rpg - 1) / rpg;
+  hipLaunchKernelGGL(colsum_stage_kernel, dim3((L + 31) / 32, groups), dim3(256), 0, stream, parts, out, nparts, L, rpg);
+  *red_ptr = out;
+  *red_rows = groups;
+  return check_launch("colsum_stage_kernel");
+}
+
+// ================================================================================================
+// BatchNorm (train): finalize batch statistics  (nn.BatchNorm2d, models/model_2.py:45,52)
+//   parts[i][0][c] = partial sum, parts[i][1][c] = partial sum of squares
+//   scale = gamma*rstd, shift = beta - mean*scale; running stats use the UNBIASED variance.
+// ================================================================================================
+__global__ void bn_finalize_kernel(const float* __restrict__ parts, int nparts, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, float* running_mean, float* running_var, float* scale,
+                                   float* shift, float* mean_out, float* rstd_out, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int i = 0; i < nparts; ++i) {
+    s += (double)parts[((long)i * 2 + 0) * C + c];
+    q += (double)parts[((long)i * 2 + 1) * C + c];
+  }
+  const double mean = s / count;
+  double var = q / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * rstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  mean_out[c] = (float)mean;
+  rstd_out[c] = rstd;
+  if (running_mean) {
+    const double unbiased = var * (count / (count > 1.0 ? count - 1.0 : 1.0));
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// BatchNorm (eval) folded with the conv bias: y = relu(acc*scale + shift)
+__global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv,
+                                      const float* __restrict__ conv_bias, float eps, float* scale, float* shift,
+                                      int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float s = gamma[c] / sqrtf(rv[c] + eps);
+  scale[c] = s;
+  shift[c] = beta[c] + ((conv_bias ? conv_bias[c] : 0.f) - rm[c]) * s;
+}
+
+// ================================================================================================
+// a = relu(scale*y + shift)  (or a = y when scale == null), optional 2x2 max-pool of a
+//   F.max_pool2d(x, 2): models/model_2.py:59-61,64.   POOL: one thread per (2x2 window, chunk).
+// ================================================================================================
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void bn_relu_apply_kernel(const ApplyParams p) {
+  constexpr int EPC = Chunk<T>::N;
+  const int cpp = p.C / EPC;                                  // chunks per pixel
+  const int Hq = POOL ? p.H / 2 : p.H, Wq = POOL ? p.W / 2 : p.W;
+  const long total = (long)p.N * Hq * Wq * cpp;
+  const T* __restrict__ yg = reinterpret_cast<const T*>(p.y);
+  T* __restrict__ ag = reinterpret_cast<T*>(p.a);
+  T* __restrict__ pg = reinterpret_cast<T*>(p.pooled);
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int ch = (int)(idx % cpp);
+    const long q = idx / cpp;
+    const int c0 = ch * EPC;
+    float sc[EPC], sh[EPC];
+    if (p.scale) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { sc[e] = p.scale[c0 + e]; sh[e] = p.shift[c0 + e]; }
+    }
+    if (!POOL) {
+      float v[EPC];
+      Chunk<T>::unpack(ld16(yg + q * p.ldy + c0), v);
+      if (p.scale) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
+      }
+      st16(ag + q * p.lda + c0, Chunk<T>::pack(v));
+    } else {
+      const int xq = (int)(q % Wq);
+      const long t2 = q / Wq;
+      const int yq = (int)(t2 % Hq), n = (int)(t2 / Hq);
+      float best[EPC];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const long pix = ((long)n * p.H + 2 * yq + (k >> 1)) * p.W + 2 * xq + (k & 1);
+        float v[EPC];
+        Chunk<T>::unpack(ld16(yg + pix * p.ldy + c0), v);
+        if (p.scale) {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) v[e] = round_through<T>(fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f));
+          if (ag) st16(ag + pix * p.lda + c0, Chunk<T>::pack(v));
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) best[e] = (k == 0) ? v[e] : fmaxf(best[e], v[e]);
+      }
+      st16(pg + q * p.ldp + c0, Chunk<T>::pack(best));
+    }
+  }
+}
+
+// ================================================================================================
+// BatchNorm+ReLU backward.  Incoming gradient dA of the activated output a = relu(scale*y+shift):
+//     dA = dskip (+ scatter of dpool to the window arg-max when POOL)
+//   dyhat = dA * [a > 0];  xhat = (y - mean)*rstd
+//   reduce:   S1 = sum dyhat, S2 = sum dyhat*xhat, S3 = sum xhat      (per channel)
+//   apply:    dy = k1*dyhat - k2 - k3*xhat,   k1 = gamma*rstd, k2 = k1*S1/M, k3 = k1*S2/M
+//   dgamma = S2, dbeta = S1, dbias(conv) = sum dy = -k3*S3  (zero up to rounding, as in the reference)
+// The pool arg-max is recomputed from y exactly as the forward pass saw it (values rounded through
+// the storage type, first maximum in row-major window order: ATen's tie rule).
+// ================================================================================================
+template <typename T, bool POOL, bool APPLY>
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdParams p) {
+  constexpr int EPC = Chunk<T>::N;
+  __shared__ float red[256 * 3 * EPC];
+  const int cpp = p.C / EPC;
+  const int tid = threadIdx.x;
+  // thread -> fixed channel chunk; pixel lanes stride over the (window) list
+  const int seg = (cpp < 256) ? cpp : 256;                 // chunk lanes per block row
+  const int plane = 256 / seg;                             // pixel lanes
+  const int chl = tid % seg, pl = tid / seg;
+  const int nseg = (cpp + seg - 1) / seg;                  // gridDim.y
+  const int ch = blockIdx.y * seg + chl;
+  const bool active = (pl < plane) && (ch < cpp);
+  const int c0 = ch * EPC;
+  const int Hq = POOL ? p.H / 2 : p.H, Wq = POOL ? p.W / 2 : p.W;
+  const long Q = (long)p.N * Hq * Wq;
+  const T* __restrict__ yg = reinterpret_cast<const T*>(p.y);
+  const T* __restrict__ sg = reinterpret_cast<const T*>(p.dskip);
+  const T* __restrict__ dpg = reinterpret_cast<const T*>(p.dpool);
+  T* __restrict__ dyg = reinterpret_cast<T*>(p.dy);
+  (void)nseg;
+
+  float sc[EPC], sh[EPC], mu[EPC], rs[EPC], k1[EPC], k2[EPC], k3[EPC];
+  float s1[EPC], s2[EPC], s3[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    s1[e] = s2[e] = s3[e] = 0.f;
+    if (active) {
+      sc[e] = p.scale[c0 + e]; sh[e] = p.shift[c0 + e]; mu[e] = p.mean[c0 + e]; rs[e] = p.rstd[c0 + e];
+      if (APPLY) { k1[e] = p.k1[c0 + e]; k2[e] = p.k2[c0 + e]; k3[e] = p.k3[c0 + e]; }
+    }
+  }
+  if (active) {
+    for (long q = (long)blockIdx.x * plane + pl; q < Q; q += (long)gridDim.x * plane) {
+      if (!POOL) {
+        float yv[EPC], g[EPC];
+        Chunk<T>::unpack(ld16(yg + q * p.ldy + c0), yv);
+        Chunk<T>::unpack(ld16(sg + q * p.lds + c0), g);
+        float out[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const float nrm = fmaf(yv[e], sc[e], sh[e]);
+          const float gh = nrm > 0.f ? g[e] : 0.f;
+          const float xh = (yv[e] - mu[e]) * rs[e];
+          if (APPLY) out[e] = fmaf(k1[e], gh, -k2[e]) - k3[e] * xh;
+          else { s1[e] += gh; s2[e] = fmaf(gh, xh, s2[e]); s3[e] += xh; }
+        }
+        if (APPLY) st16(dyg + q * p.lddy + c0, Chunk<T>::pack(out));
+      } else {
+        const int xq = (int)(q % Wq);
+        const long t2 = q / Wq;
+        const int yq = (int)(t2 % Hq), n = (int)(t2 / Hq);
+        float yv[4][EPC], dp[EPC];
+        long pix[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          pix[k] = ((long)n * p.H + 2 * yq + (k >> 1)) * p.W + 2 * xq + (k & 1);
+          Chunk<T>::unpack(ld16(yg + pix[k] * p.ldy + c0), yv[k]);
+        }
+        Chunk<T>::unpack(ld16(dpg + q * p.ldp + c0), dp);
+        int arg[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          float best = 0.f;
+          arg[e] = 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float a = round_through<T>(fmaxf(fmaf(yv[k][e], sc[e], sh[e]), 0.f));
+            if (k == 0 || a > best) { best = a; arg[e] = k; }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float g[EPC], out[EPC];
+          if (sg) Chunk<T>::unpack(ld16(sg + pix[k] * p.lds + c0), g);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            const float gin = (sg ? g[e] : 0.f) + (arg[e] == k ? dp[e] : 0.f);
+            const float nrm = fmaf(yv[k][e], sc[e], sh[e]);
+            const float gh = nrm > 0.f ? gin : 0.f;
+            const float xh = (yv[k][e] - mu[e]) * rs[e];
+            if (APPLY) out[e] = fmaf(k1[e], gh, -k2[e]) - k3[e] * xh;
+            else { s1[e] += gh; s2[e] = fmaf(gh, xh, s2[e]); s3[e] += xh; }
+          }
+          if (APPLY) st16(dyg + pix[k] * p.lddy + c0, Chunk<T>::pack(out));
+        }
+      }
+    }
+  }
+  if (!APPLY) {
+    // block reduction over pixel lanes (fixed order)
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      red[(tid * 3 + 0) * EPC + e] = s1[e];
+      red[(tid * 3 + 1) * EPC + e] = s2[e];
+      red[(tid * 3 + 2) * EPC + e] = s3[e];
+    }
+    __syncthreads();
+    // one thread per (chunk lane, which, element)
+    for (int i = tid; i < seg * 3 * EPC; i += 256) {
+      const int cl = i / (3 * EPC), rem = i - cl * 3 * EPC, which = rem / EPC, e = rem - which * EPC;
+      const int chn = blockIdx.y * seg + cl;
+      if (chn >= cpp) continue;
+      float s = 0.f;
+      for (int q2 = 0; q2 < plane; ++q2) s += red[((q2 * seg + cl) * 3 + which) * EPC + e];
+      p.parts[((long)blockIdx.x * 3 + which) * p.C + chn * EPC + e] = s;
+    }
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ parts, int nparts, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ rstd,
+                                       float* dgamma, float* dbeta, float* dbias, float* k1, float* k2, float* k3,
+                                       int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  for (int i = 0; i < nparts; ++i) {
+    s1 += (double)parts[((long)i * 3 + 0) * C + c];
+    s2 += (double)parts[((long)i * 3 + 1) * C + c];
+    s3 += (double)parts[((long)i * 3 + 2) * C + c];
+  }
+  const double a = (double)gamma[c] * (double)rstd[c];
+  dgamma[c] = (float)s2;
+  dbeta[c] = (float)s1;
+  k1[c] = (float)a;
+  k2[c] = (float)(a * s1 / count);
+  k3[c] = (float)(a * s2 / count);
+  if (dbias) dbias[c] = (float)(-(a * s2 / count) * s3);
+}
+
+// ================================================================================================
+// Head: 1x1 conv (C -> OC) + sigmoid (models/model_2.py:32,79-80), probabilities out in NCHW fp32.
+// C/EPC lanes cooperate on one pixel (C = 64: 8 lanes bf16 / 16 lanes fp32), shuffle-reduced.
+// ================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const HeadParams p) {
+  constexpr int EPC = Chunk<T>::N;
+  const int cpp = p.C / EPC;                          // lanes per pixel (power of two, <= 64)
+  const int ppb = 256 / cpp;
+  const int tid = threadIdx.x, cl = tid % cpp, pl = tid / cpp;
+  const long HW = (long)p.H * p.W, P = (long)p.N * HW;
+  const T* __restrict__ ag = reinterpret_cast<const T*>(p.a);
+  for (long pb = (long)blockIdx.x * ppb; pb < P; pb += (long)gridDim.x * ppb) {
+    const long pix = pb + pl;
+    const bool ok = pix < P;
+    float v[EPC];
+    if (ok) Chunk<T>::unpack(ld16(ag + pix * p.lda + cl * EPC), v);
+    for (int oc = 0; oc < p.OC; ++oc) {
+      float s = 0.f;
+      if (ok) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) s = fmaf(v[e], p.w[oc * p.C + cl * EPC + e], s);
+      }
+      for (int o = 1; o < cpp; o <<= 1) s += __shfl_xor(s, o, 64);
+      if (ok && cl == 0) {
+        const float z = s + p.b[oc];
+        const long n = pix / HW, rem = pix - n * HW;
+        p.probs[(n * p.OC + oc) * HW + rem] = 1.f / (1.f + expf(-z));
+      }
+    }
+  }
+}
+
+// dz = dp * p * (1-p);  dA[pix][c] = sum_oc dz[oc]*w[oc][c];  partial sums of dz*a (dW) and dz (db)
+// parts layout: [gridDim.x][OC][C + 1]   (last column = bias gradient)
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const HeadParams p) {
+  constexpr int EPC = Chunk<T>::N;
+  __shared__ float red[256 * (EPC + 1)];
+  const int cpp = p.C / EPC, ppb = 256 / cpp;
+  const int tid = threadIdx.x, cl = tid % cpp, pl = tid / cpp;
+  const long HW = (long)p.H * p.W, P = (long)p.N * HW;
+  const T* __restrict__ ag = reinterpret_cast<const T*>(p.a);
+  T* __restrict__ dag = reinterpret_cast<T*>(p.da);
+  for (int oc = 0; oc < p.OC; ++oc) {
+    float wv[EPC], gw[EPC], gb = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { wv[e] = p.w[oc * p.C + cl * EPC + e]; gw[e] = 0.f; }
+    for (long pb = (long)blockIdx.x * ppb; pb < P; pb += (long)gridDim.x * ppb) {
+      const long pix = pb + pl;
+      if (pix >= P) continue;
+      const long n = pix / HW, rem = pix - n * HW;
+      const long o = (n * p.OC + oc) * HW + rem;
+      const float pr = p.probs[o];
+      const float dz = p.dprobs[o] * pr * (1.f - pr);
+      float av[EPC], d[EPC];
+      Chunk<T>::unpack(ld16(ag + pix * p.lda + cl * EPC), av);
+      if (oc > 0) Chunk<T>::unpack(ld16(dag + pix * p.ldda + cl * EPC), d);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        gw[e] = fmaf(dz, av[e], gw[e]);
+        d[e] = (oc > 0 ? d[e] : 0.f) + dz * wv[e];
+      }
+      if (cl == 0) gb += dz;
+      st16(dag + pix * p.ldda + cl * EPC, Chunk<T>::pack(d));
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) red[tid * (EPC + 1) + e] = gw[e];
+    red[tid * (EPC + 1) + EPC] = gb;
+    __syncthreads();
+    for (int i = tid; i < p.C + 1; i += 256) {
+      float s = 0.f;
+      if (i < p.C) {
+        const int c2 = i / EPC, e = i % EPC;
+        for (int q = 0; q < ppb; ++q) s += red[(q * cpp + c2) * (EPC + 1) + e];
+      } else {
+        for (int q = 0; q < ppb; ++q) s += red[(q * cpp) * (EPC + 1) + EPC];
+      }
+      p.parts[((long)blockIdx.x * p.OC + oc) * (p.C + 1) + i] = s;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void head_bwd_finalize_kernel(const float* __restrict__ parts, int nparts, float* dw, float* db, int OC,
+                                         int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int L = OC * (C + 1);
+  if (i >= L) return;
+  double s = 0.0;
+  for (int q = 0; q < nparts; ++q) s += (double)parts[(long)q * L + i];
+  const int oc = i / (C + 1), c = i - oc * (C + 1);
+  if (c < C) dw[oc * C + c] = (float)s;
+  else db[oc] = (float)s;
+}
+
+// ================================================================================================
+// per-channel sum over pixels of an NHWC tensor (ConvTranspose2d bias gradient)
+// parts layout: [gridDim.x][C]
+// ================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const void* __restrict__ x, int ldx, float* __restrict__ parts,
+                                                          long P, int C) {
+  constexpr int EPC = Chunk<T>::N;
+  __shared__ float red[256 * EPC];
+  const int cpp = C / EPC;
+  const int tid = threadIdx.x;
+  const int seg = (cpp < 256) ? cpp : 256, plane = 256 / seg;
+  const int chl = tid % seg, pl = tid / seg;
+  const int ch = blockIdx.y * seg + chl;
+  const T* __restrict__ xg = reinterpret_cast<const T*>(x);
+  float s[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) s[e] = 0.f;
+  if (ch < cpp)
+    for (long q = (long)blockIdx.x * plane + pl; q < P; q += (long)gridDim.x * plane) {
+      float v[EPC];
+      Chunk<T>::unpack(ld16(xg + q * ldx + ch * EPC), v);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) s[e] += v[e];
+    }
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) red[tid * EPC + e] = s[e];
+  __syncthreads();
+  for (int i = tid; i < seg * EPC; i += 256) {
+    const int cl = i / EPC, e = i - cl * EPC;
+    const int chn = blockIdx.y * seg + cl;
+    if (chn >= cpp) continue;
+    float t = 0.f;
+    for (int q2 = 0; q2 < plane; ++q2) t += red[(q2 * seg + cl) * EPC + e];
+    parts[(long)blockIdx.x * C + chn * EPC + e] = t;
+  }
+}
+
+__global__ void channel_sum_finalize_kernel(const float* __restrict__ parts, int nparts, float* out, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int i = 0; i < nparts; ++i) s += (double)parts[(long)i * C + c];
+  out[c] = (float)s;
+}
+
+// ================================================================================================
+// Weight packing (fp32 PyTorch layouts -> K-contiguous "[tap][out][in]" images in the compute type)
+// ================================================================================================
+template <typename T>
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int Co, int Ci) {
+  const long n = (long)Co * Ci * 9;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    // i indexes the forward image [t][co][ci]
+    const int ci = (int)(i % Ci);
+    const long r = i / Ci;
+    const int co = (int)(r % Co), t = (int)(r / Co);
+    const float v = w[((long)co * Ci + ci) * 9 + t];
+    wf[i] = from_f32<T>(v);
+    // dgrad image [t'][ci][co] with t' = 8 - t (both spatial axes flipped)
+    if (wd) wd[((long)(8 - t) * Ci + ci) * Co + co] = from_f32<T>(v);
+  }
+}
+
+template <typename T>
+__global__ void pack_convT2x2_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int Ci, int Co) {
+  const long n = (long)Ci * Co * 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    // i indexes the forward image [(ab)*Co + co][ci]
+    const int ci = (int)(i % Ci);
+    const long r = i / Ci;
+    const int co = (int)(r % Co), ab = (int)(r / Co);
+    const float v = w[((long)ci * Co + co) * 4 + ab];
+    wf[i] = from_f32<T>(v);
+    if (wd) wd[((long)ab * Ci + ci) * Co + co] = from_f32<T>(v);    // dgrad image [ab][ci][co]
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------
+static int grid_for(long work_items, int per_block) {
+  long nb = (work_items + per_block - 1) / per_block;
+  if (nb > 8192) nb = 8192;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+int launch_bn_finalize(const float* parts, int nparts, long count, const float* gamma, const float* beta, float eps,
+                       float momentum, float* rm, float* rv, float* scale, float* shift, float* mean, float* rstd,
+                       int C, hipStream_t stream) {
+  UNETDC_REQUIRE(parts && gamma && beta && scale && shift && mean && rstd, "bn_finalize: null pointer");
+  UNETDC_REQUIRE(nparts > 0 && count > 0 && C > 0, "bn_finalize: empty problem");
+  const float* rp; int rows;
+  int rc = reduce_parts(parts, nparts, 2 * C, &rp, &rows, stream);
+  if (rc != UNETDC_OK) return rc;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, rp, rows, (double)count, gamma,
+                     beta, eps, momentum, rm, rv, scale, shift, mean, rstd, C);
+  return check_launch("bn_finalize_kernel");
+}
+
+int launch_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv,
+                          const float* conv_bias, float eps, float* scale, float* shift, int C, hipStream_t stream) {
+  UNETDC_REQUIRE(gamma && beta && rm && rv && scale && shift, "bn_eval_affine: null pointer");
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, gamma, beta, rm, rv, conv_bias,
+                     eps, scale, shift, C);
+  return check_launch("bn_eval_affine_kernel");
+}
+
+int launch_apply(ApplyParams& p, int dtype, hipStream_t stream) {
+  const int epc = dtype == UNETDC_BF16 ? 8 : 4;
+  UNETDC_REQUIRE(dtype == UNETDC_F32 || dtype == UNETDC_BF16, "bn_relu_apply: bad dtype %d", dtype);
+  UNETDC_REQUIRE(p.y, "bn_relu_apply: null input");
+  UNETDC_REQUIRE(p.C % epc == 0 && p.ldy % epc == 0, "bn_relu_apply: C/ld not chunk aligned");
+  UNETDC_REQUIRE((p.scale == nullptr) == (p.shift == nullptr), "bn_relu_apply: scale/shift mismatch");
+  const bool pool = p.pooled != nullptr;
+  if (pool) UNETDC_REQUIRE(p.H % 2 == 0 && p.W % 2 == 0 && p.ldp % epc == 0, "bn_relu_apply: pooling needs even H, W");
+  if (!pool) UNETDC_REQUIRE(p.a != nullptr, "bn_relu_apply: nothing to write");
+  if (p.a) UNETDC_REQUIRE(p.lda % epc == 0, "bn_relu_apply: lda not chunk aligned");
+  const long items = (long)p.N * (pool ? p.H / 2 : p.H) * (pool ? p.W / 2 : p.W) * (p.C / epc);
+  const int nb = grid_for(items, 256);
+  if (dtype == UNETDC_BF16) {
+    if (pool) hipLaunchKernelGGL((bn_relu_apply_kernel<bf16_t, true>), dim3(nb), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((bn_relu_apply_kernel<bf16_t, false>), dim3(nb), dim3(256), 0, stream, p);
+  } else {
+    if (pool) hipLaunchKernelGGL((bn_relu_apply_kernel<float, true>), dim3(nb), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((bn_relu_apply_kernel<float, false>), dim3(nb), dim3(256), 0, stream, p);
+  }
+  return check_launch("bn_relu_apply_kernel");
+}
+
+// workspace floats needed by launch_bn_bwd: (nblk + 64) * 3 * C + 3 * C
+static int bn_bwd_blocks(long Q, int cpp) {
+  const int seg = cpp < 256 ? cpp : 256;
+  const int plane = 256 / seg;
+  long nb = (Q + (long)plane * 8 - 1) / ((long)plane * 8);     // >= 8 items per pixel lane
+  if (nb > 512) nb = 512;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+long bn_bwd_workspace_bytes(int N, int H, int W, int C, int pooled, int dtype) {
+  const int epc = dtype == UNETDC_BF16 ? 8 : 4;
+  const long Q = (long)N * (pooled ? H / 2 : H) * (pooled ? W / 2 : W);
+  const int nb = bn_bwd_blocks(Q, C / epc);
+  return ((long)(nb + 64) * 3 * C + 3 * C) * 4;
+}
+
+template <typename T>
+static void launch_bn_bwd_k(const BnBwdParams& p, bool pool, bool apply, dim3 grid, hipStream_t stream) {
+  if (pool) {
+    if (apply) hipLaunchKernelGGL((bn_bwd_kernel<T, true, true>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((bn_bwd_kernel<T, true, false>), grid, dim3(256), 0, stream, p);
+  } else {
+    if (apply) hipLaunchKernelGGL((bn_bwd_kernel<T, false, true>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((bn_bwd_kernel<T, false, false>), grid, dim3(256), 0, stream, p);
+  }
+}
+
+int launch_bn_bwd(BnBwdParams& p, const float* gamma, float* dgamma, float* dbeta, float* dbias, void* workspace,
+                  long workspace_bytes, int dtype, hipStream_t stream) {
+  const int epc = dtype == UNETDC_BF16 ? 8 : 4;
+  UNETDC_REQUIRE(dtype == UNETDC_F32 || dtype == UNETDC_BF16, "bn_bwd: bad dtype %d", dtype);
+  UNETDC_REQUIRE(p.y && p.dy && (p.dskip || p.dpool), "bn_bwd: null tensor");
+  UNETDC_REQUIRE(p.scale && p.shift && p.mean && p.rstd && gamma && dgamma && dbeta && workspace, "bn_bwd: null pointer");
+  UNETDC_REQUIRE(p.C % epc == 0 && p.ldy % epc == 0 && p.lddy % epc == 0, "bn_bwd: C/ld not chunk aligned");
+  const bool pool = p.dpool != nullptr;
+  if (pool) UNETDC_REQUIRE(p.H % 2 == 0 && p.W % 2 == 0 && p.ldp % epc == 0, "bn_bwd: pooling needs even H, W");
+  if (!pool) UNETDC_REQUIRE(p.dskip != nullptr, "bn_bwd: gradient missing");
+  if (p.dskip) UNETDC_REQUIRE(p.lds % epc == 0, "bn_bwd: lds not chunk aligned");
+  const int cpp = p.C / epc;
+  const int seg = cpp < 256 ? cpp : 256;
+  UNETDC_REQUIRE(256 % seg == 0, "bn_bwd: C=%d unsupported (C/%d must divide 256 or be a multiple of 256)", p.C, epc);
+  const long Q = (long)p.N * (pool ? p.H / 2 : p.H) * (pool ? p.W / 2 : p.W);
+  const int nb = bn_bwd_blocks(Q, cpp);
+  const long need = ((long)(nb + 64) * 3 * p.C + 3 * p.C) * 4;
+  if (need > workspace_bytes) {
+    set_error("bn_bwd: workspace too small (%ld < %ld bytes)", workspace_bytes, need);
+    return UNETDC_EWORKSPACE;
+  }
+  float* ws = reinterpret_cast<float*>(workspace);
+  float* k = ws;                         // k1,k2,k3
+  float* parts = ws + 3 * p.C;
+  p.parts = parts;
+  p.k1 = k; p.k2 = k + p.C; p.k3 = k + 2 * p.C;
+  const dim3 grid(nb, (cpp + seg - 1) / seg);
+  if (dtype == UNETDC_BF16) launch_bn_bwd_k<bf16_t>(p, pool, false, grid, stream);
+  else launch_bn_bwd_k<float>(p, pool, false, grid, stream);
+  int rc = check_launch("bn_bwd_kernel(reduce)");
+  if (rc != UNETDC_OK) return rc;
+  const float* rp; int rows;
+  rc = reduce_parts(parts, nb, 3 * p.C, &rp, &rows, stream);
+  if (rc != UNETDC_OK) return rc;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 63) / 64), dim3(64), 0, stream, rp, rows,
+                     (double)p.N * p.H * p.W, gamma, p.rstd, dgamma, dbeta, dbias, k, k + p.C, k + 2 * p.C, p.C);
+  rc = check_launch("bn_bwd_finalize_kernel");
+  if (rc != UNETDC_OK) return rc;
+  const long items = Q * cpp;
+  const dim3 grid2(grid_for(items, 256) > 4096 ? 4096 : grid_for(items, 256), (cpp + seg - 1) / seg);
+  if (dtype == UNETDC_BF16) launch_bn_bwd_k<bf16_t>(p, pool, true, grid2, stream);
+  else launch_bn_bwd_k<float>(p, pool, true, grid2, stream);
+  return check_launch("bn_bwd_kernel(apply)");
+}
+
+static int head_blocks(long P, int cpp) {
+  long nb = (P + (256 / cpp) * 8 - 1) / ((256 / cpp) * 8);
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+long head_bwd_workspace_bytes(int N, int H, int W, int C, int OC, int dtype) {
+  const int epc = dtype == UNETDC_BF16 ? 8 : 4;
+  return ((long)head_blocks((long)N * H * W, C / epc) + 64) * OC * (C + 1) * 4;
+}
+
+static int check_head(const HeadParams& p, int dtype) {
+  const int epc = dtype == UNETDC_BF16 ? 8 : 4;
+  UNETDC_REQUIRE(dtype == UNETDC_F32 || dtype == UNETDC_BF16, "head: bad dtype %d", dtype);
+  UNETDC_REQUIRE(p.a && p.w && p.probs, "head: null pointer");
+  const int cpp = p.C / epc;
+  UNETDC_REQUIRE(p.C % epc == 0 && cpp >= 1 && cpp <= 64 && (cpp & (cpp - 1)) == 0,
+                 "head: C=%d unsupported (C/%d must be a power of two <= 64)", p.C, epc);
+  UNETDC_REQUIRE(p.lda % epc == 0 && p.OC >= 1, "head: bad lda/OC");
+  return UNETDC_OK;
+}
+
+int launch_head_fwd(HeadParams& p, int dtype, hipStream_t stream) {
+  int rc = check_head(p, dtype);
+  if (rc != UNETDC_OK) return rc;
+  UNETDC_REQUIRE(p.b != nullptr, "head: null bias");
+  const int epc = dtype == UNETDC_BF16 ? 8 : 4;
+  const int nb = grid_for((long)p.N * p.H * p.W, 256 / (p.C / epc));
+  if (dtype == UNETDC_BF16) hipLaunchKernelGGL(head_fwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(nb), dim3(256), 0, stream, p);
+  return check_launch("head_fwd_kernel");
+}
+
+int launch_head_bwd(HeadParams& p, float* dw, float* db, void* workspace, long workspace_bytes, int dtype,
+                    hipStream_t stream) {
+  int rc = check_head(p, dtype);
+  if (rc != UNETDC_OK) return rc;
+  UNETDC_REQUIRE(p.dprobs && p.da && dw && db && workspace, "head_bwd: null pointer");
+  const int epc = dtype == UNETDC_BF16 ? 8 : 4;
+  UNETDC_REQUIRE(p.ldda % epc == 0, "head_bwd: ldda not chunk aligned");
+  const int nb = head_blocks((long)p.N * p.H * p.W, p.C / epc);
+  const long need = ((long)nb + 64) * p.OC * (p.C + 1) * 4;
+  if (need > workspace_bytes) {
+    set_error("head_bwd: workspace too small (%ld < %ld bytes)", workspace_bytes, need);
+    return UNETDC_EWORKSPACE;
+  }
+  p.parts = reinterpret_cast<float*>(workspace);
+  if (dtype == UNETDC_BF16) hipLaunchKernelGGL(head_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(head_bwd_kernel<float>, dim3(nb), dim3(256), 0, stream, p);
+  rc = check_launch("head_bwd_kernel");
+  if (rc != UNETDC_OK) return rc;
+  const int L = p.OC * (p.C + 1);
+  const float* rp; int rows;
+  rc = reduce_parts(p.parts, nb, L, &rp, &rows, stream);
+  if (rc != UNETDC_OK) return rc;
+  hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3((L + 63) / 64), dim3(64), 0, stream, rp, rows, dw, db, p.OC, p.C);
+  return check_launch("head_bwd_finalize_kernel");
+}
+
+int launch_pack_conv3x3(const float* w, void* wf, void* wd, int Co, int Ci, int dtype, hipStream_t stream) {
+  UNETDC_REQUIRE(w && wf, "pack_conv3x3: null pointer");
+  UNETDC_REQUIRE(dtype == UNETDC_F32 || dtype == UNETDC_BF16, "pack_conv3x3: bad dtype %d", dtype);
+  const int nb = grid_for((long)Co * Ci * 9, 256);
+  if (dtype == UNETDC_BF16)
+    hipLaunchKernelGGL(pack_conv3x3_kernel<bf16_t>, dim3(nb), dim3(256), 0, stream, w, (bf16_t*)wf, (bf16_t*)wd, Co, Ci);
+  else
+    hipLaunchKernelGGL(pack_conv3x3_kernel<float>, dim3(nb), dim3(256), 0, stream, w, (float*)wf, (float*)wd, Co, Ci);
+  return check_launch("pack_conv3x3_kernel");
+}
+
+int launch_pack_convT2x2(const float* w, void* wf, void* wd, int Ci, int Co, int dtype, hipStream_t stream) {
+  UNETDC_REQUIRE(w && wf, "pack_convT2x2: null pointer");
+  UNETDC_REQUIRE(dtype == UNETDC_F32 || dtype == UNETDC_BF16, "pack_convT2x2: bad dtype %d", dtype);
+  const int nb = grid_for((long)Co * Ci * 4, 256);
+  if (dtype == UNETDC_BF16)
+    hipLaunchKernelGGL(pack_convT2x2_kernel<bf16_t>, dim3(nb), dim3(256), 0, stream, w, (bf16_t*)wf, (bf16_t*)wd, Ci, Co);
+  else
+    hipLaunchKernelGGL(pack_convT2x2_kernel<float>, dim3(nb), dim3(256), 0, stream, w, (float*)wf, (float*)wd, Ci, Co);
+  return check_launch("pack_convT2x2_kernel");
+}
+
+static int channel_sum_blocks(long P) {
+  long nb = (P + 63) / 64;
+  if (nb > 512) nb = 512;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+long channel_sum_workspace_bytes(long P, int C) { return ((long)channel_sum_blocks(P) + 64) * C * 4; }
+
+int launch_channel_sum(const void* x, int ldx, float* out, void* workspace, long workspace_bytes, long P, int C,
+                       int dtype, hipStream_t stream) {
+  const int epc = dtype == UNETDC_BF16 ? 8 : 4;
+  UNETDC_REQUIRE(dtype == UNETDC_F32 || dtype == UNETDC_BF16, "channel_sum: bad dtype %d", dtype);
+  UNETDC_REQUIRE(x && out && workspace && P > 0, "channel_sum: null pointer / empty");
+  UNETDC_REQUIRE(C % epc == 0 && ldx % epc == 0, "channel_sum: C/ld not chunk aligned");
+  const int cpp = C / epc, seg = cpp < 256 ? cpp : 256;
+  UNETDC_REQUIRE(256 % seg == 0, "channel_sum: C=%d unsupported", C);
+  const int nb = channel_sum_blocks(P);
+  const long need = ((long)nb + 64) * C * 4;
+  if (need > workspace_bytes) {
+    set_error("channel_sum: workspace too small (%ld < %ld bytes)", workspace_bytes, need);
+    return UNETDC_EWORKSPACE;
+  }
+  float* parts = reinterpret_cast<float*>(workspace);
+  const dim3 grid(nb, (cpp + seg - 1) / seg);
+  if (dtype == UNETDC_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, grid, dim3(256), 0, stream, x, ldx, parts, P, C);
+  else hipLaunchKernelGGL(channel_sum_kernel<float>, grid, dim3(256), 0, stream, x, ldx, parts, P, C);
+  int rc = check_launch("channel_sum_kernel");
+  if (rc != UNETDC_OK) return rc;
+  const float* rp; int rows;
+  rc = reduce_parts(parts, nb, C, &rp, &rows, stream);
+  if (rc != UNETDC_OK) return rc;
+  hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, rp, rows, out, C);
+  return check_launch("channel_sum_finalize_kernel");
+}
+
+}  // namespace unetdc

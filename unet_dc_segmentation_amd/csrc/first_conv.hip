@@ -1,0 +1,232 @@
+// First encoder convolution (enc1.0: Cin = 1 or 3 -> 64, models/model_2.py:10,41-44).
+//
+// K = 9*Cin is far too short for the matrix cores and the layer is HBM-bound on its OUTPUT
+// (arithmetic intensity 4.4 FLOP/B), so this is a direct VALU kernel:
+//   * reads the caller's NCHW fp32 image as it is (no layout pass; a C=1 image is already NHWC),
+//   * 8 consecutive lanes own one pixel and write its 64 channels as 8 x 16-byte chunks
+//     = one contiguous 128/256-byte NHWC row,
+//   * weights live in LDS as [tap*Cin + ci][Cout] fp32, read as two ds_read_b128 per tap,
+//   * BatchNorm batch statistics (sum, sum of squares of the stored values) are reduced per block.
+// The matching weight gradient streams dY once per input channel and keeps the 9 x 8 products per
+// lane in registers; block partials are summed by a second deterministic kernel.
+#include "kernels.h"
+
+namespace unetdc {
+
+template <typename T>
+__global__ __launch_bounds__(256) void first_conv_fwd_kernel(const FirstParams p) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];     // [9*Cin][Cout] + reduction scratch
+  const int tid = threadIdx.x;
+  const int G = p.Cout / 8;                 // lanes per pixel
+  const int PPB = 256 / G;                  // pixels per block iteration
+  const int K = 9 * p.Cin;
+  for (int i = tid; i < K * p.Cout; i += 256) {
+    const int co = i % p.Cout, k = i / p.Cout;          // k = tap*Cin + ci
+    const int tap = k / p.Cin, ci = k - tap * p.Cin;
+    wl[i] = p.w[(co * p.Cin + ci) * 9 + tap];
+  }
+  __syncthreads();
+  const int g = tid % G, pl = tid / G;
+  const int HW = p.H * p.W;
+  const long P = (long)p.N * HW;
+  float k0[8], k1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int co = g * 8 + e;
+    k0[e] = p.scale ? p.scale[co] : 1.f;
+    k1[e] = p.scale ? p.shift[co] : (p.bias ? p.bias[co] : 0.f);
+  }
+  float su[8], sq[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) su[e] = sq[e] = 0.f;
+  T* __restrict__ yg = reinterpret_cast<T*>(p.y);
+
+  for (long pb = (long)blockIdx.x * PPB; pb < P; pb += (long)gridDim.x * PPB) {
+    const long pix = pb + pl;
+    if (pl < PPB && pix < P) {
+      const int n = (int)(pix / HW), rem = (int)(pix - (long)n * HW);
+      const int y = rem / p.W, x = rem - y * p.W;
+      float acc[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+      for (int tap = 0; tap < 9; ++tap) {
+        const int iy = y + (tap / 3 - 1) * p.dil, ix = x + (tap % 3 - 1) * p.dil;
+        if ((unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.W) continue;
+        for (int ci = 0; ci < p.Cin; ++ci) {
+          const float xv = p.x[((long)(n * p.Cin + ci) * p.H + iy) * p.W + ix];
+          const float* wr = wl + (tap * p.Cin + ci) * p.Cout + g * 8;
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr), w1 = *reinterpret_cast<const f32x4*>(wr + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc[e] = fmaf(xv, w0[e], acc[e]);
+            acc[4 + e] = fmaf(xv, w1[e], acc[4 + e]);
+          }
+        }
+      }
+      float out[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = p.scale ? fmaxf(fmaf(acc[e], k0[e], k1[e]), 0.f) : acc[e] + k1[e];
+        out[e] = round_through<T>(v);              // statistics of the values as stored
+        su[e] += out[e];
+        sq[e] = fmaf(out[e], out[e], sq[e]);
+      }
+      T* dst = yg + pix * p.ldy + g * 8;
+#pragma unroll
+      for (int q = 0; q < 8 / Chunk<T>::N; ++q) st16(dst + q * Chunk<T>::N, Chunk<T>::pack(out + q * Chunk<T>::N));
+    }
+  }
+  if (p.stats) {
+    // block reduction over the PPB pixel lanes that share a channel group (fixed order)
+    __syncthreads();
+    float* red = wl + K * p.Cout;                     // [256][16]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[tid * 16 + e] = su[e];
+      red[tid * 16 + 8 + e] = sq[e];
+    }
+    __syncthreads();
+    if (tid < p.Cout * 2) {
+      const int which = tid / p.Cout, co = tid - which * p.Cout;
+      const int gg = co / 8, e = co % 8;
+      float s = 0.f;
+      for (int q = 0; q < PPB; ++q) s += red[(q * G + gg) * 16 + which * 8 + e];
+      p.stats[((long)blockIdx.x * 2 + which) * p.Cout + co] = s;
+    }
+  }
+}
+
+// ---- weight gradient of the first layer -------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void first_conv_wgrad_kernel(const FirstWgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) float red[];    // [4 waves][G][72]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = p.Cout / 8, PPB = 256 / G;
+  const int g = tid % G, pl = tid / G;
+  const int ci = blockIdx.y;
+  const int HW = p.H * p.W;
+  const long P = (long)p.N * HW;
+  const T* __restrict__ dyg = reinterpret_cast<const T*>(p.dy);
+  float acc[9][8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+
+  for (long pb = (long)blockIdx.x * PPB; pb < P; pb += (long)gridDim.x * PPB) {
+    const long pix = pb + pl;
+    if (pl < PPB && pix < P) {
+      const int n = (int)(pix / HW), rem = (int)(pix - (long)n * HW);
+      const int y = rem / p.W, x = rem - y * p.W;
+      float d[8];
+#pragma unroll
+      for (int q = 0; q < 8 / Chunk<T>::N; ++q)
+        Chunk<T>::unpack(ld16(dyg + pix * p.lddy + g * 8 + q * Chunk<T>::N), d + q * Chunk<T>::N);
+      const float* xp = p.x + (long)(n * p.Cin + ci) * HW;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = y + (t / 3 - 1) * p.dil, ix = x + (t % 3 - 1) * p.dil;
+        float xv = 0.f;
+        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) xv = xp[iy * p.W + ix];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[t][e] = fmaf(xv, d[e], acc[t][e]);
+      }
+    }
+  }
+  // reduce over the pixel lanes of a wave that share g (lanes g, g+G, g+2G, ...), fixed xor tree
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = acc[t][e];
+      for (int o = G; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+      acc[t][e] = v;
+    }
+  if (lane < G) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[(wave * G + lane) * 72 + t * 8 + e] = acc[t][e];
+  }
+  __syncthreads();
+  for (int i = tid; i < 9 * p.Cout; i += 256) {
+    const int t = i / p.Cout, co = i - t * p.Cout, gg = co / 8, e = co % 8;
+    float s = 0.f;
+    for (int w2 = 0; w2 < 4; ++w2) s += red[(w2 * G + gg) * 72 + t * 8 + e];
+    p.part[(((long)blockIdx.x * p.Cin + ci) * 9 + t) * p.Cout + co] = s;
+  }
+}
+
+// dw[co][ci][t] = sum_blk part[blk][ci][t][co]
+__global__ void first_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nblk, int Cin,
+                                          int Cout) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = Cin * 9 * Cout;
+  if (i >= n) return;
+  const int co = i % Cout, k = i / Cout;        // k = ci*9 + t
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += part[(long)b * n + i];
+  dw[(long)co * Cin * 9 + k] = s;
+}
+
+static int first_blocks(long P, int Cout) {
+  const int ppb = 256 / (Cout / 8);
+  long nb = (P + ppb - 1) / ppb;
+  if (nb > 2048) nb = 2048;
+  return (int)nb;
+}
+
+int first_conv_mblocks(long P, int Cout) { return first_blocks(P, Cout); }
+
+int launch_first_fwd(FirstParams& p, int dtype, hipStream_t stream) {
+  UNETDC_REQUIRE(dtype == UNETDC_F32 || dtype == UNETDC_BF16, "first_conv: bad dtype %d", dtype);
+  UNETDC_REQUIRE(p.x && p.w && p.y, "first_conv: null pointer");
+  UNETDC_REQUIRE(p.Cin >= 1 && p.Cin <= 8, "first_conv: Cin=%d unsupported (1..8)", p.Cin);
+  UNETDC_REQUIRE(p.Cout % 8 == 0 && p.Cout >= 8 && p.Cout / 8 <= 16 && 64 % (p.Cout / 8) == 0,
+                 "first_conv: Cout=%d unsupported (8,16,32,64,128)", p.Cout);
+  UNETDC_REQUIRE(p.ldy % 8 == 0 && (uintptr_t)p.y % 16 == 0, "first_conv: output not 16-byte aligned");
+  const long P = (long)p.N * p.H * p.W;
+  const int nb = first_blocks(P, p.Cout);
+  const size_t lds = (size_t)(9 * p.Cin * p.Cout + 256 * 16) * 4;
+  if (dtype == UNETDC_BF16)
+    hipLaunchKernelGGL(first_conv_fwd_kernel<bf16_t>, dim3(nb), dim3(256), lds, stream, p);
+  else
+    hipLaunchKernelGGL(first_conv_fwd_kernel<float>, dim3(nb), dim3(256), lds, stream, p);
+  return check_launch("first_conv_fwd_kernel");
+}
+
+long first_wgrad_workspace_bytes(long P, int Cin, int Cout) {
+  long nb = first_blocks(P, Cout);
+  if (nb > 512) nb = 512;
+  return nb * Cin * 9 * Cout * 4;
+}
+
+int launch_first_wgrad(FirstWgradParams& p, float* dw, void* workspace, long workspace_bytes, int dtype,
+                       hipStream_t stream) {
+  UNETDC_REQUIRE(dtype == UNETDC_F32 || dtype == UNETDC_BF16, "first_wgrad: bad dtype %d", dtype);
+  UNETDC_REQUIRE(p.x && p.dy && dw && workspace, "first_wgrad: null pointer");
+  UNETDC_REQUIRE(p.Cin >= 1 && p.Cin <= 8, "first_wgrad: Cin=%d unsupported", p.Cin);
+  UNETDC_REQUIRE(p.Cout % 8 == 0 && p.Cout / 8 <= 16 && 64 % (p.Cout / 8) == 0, "first_wgrad: Cout=%d unsupported", p.Cout);
+  const long P = (long)p.N * p.H * p.W;
+  long nb = first_blocks(P, p.Cout);
+  if (nb > 512) nb = 512;
+  const long need = nb * p.Cin * 9 * p.Cout * 4;
+  if (need > workspace_bytes) {
+    set_error("first_wgrad: workspace too small (%ld < %ld bytes)", workspace_bytes, need);
+    return UNETDC_EWORKSPACE;
+  }
+  p.part = reinterpret_cast<float*>(workspace);
+  const size_t lds = (size_t)4 * (p.Cout / 8) * 72 * 4;
+  if (dtype == UNETDC_BF16)
+    hipLaunchKernelGGL(first_conv_wgrad_kernel<bf16_t>, dim3((unsigned)nb, p.Cin), dim3(256), lds, stream, p);
+  else
+    hipLaunchKernelGGL(first_conv_wgrad_kernel<float>, dim3((unsigned)nb, p.Cin), dim3(256), lds, stream, p);
+  int rc = check_launch("first_conv_wgrad_kernel");
+  if (rc != UNETDC_OK) return rc;
+  const int n = p.Cin * 9 * p.Cout;
+  hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p.part, dw, (int)nb,
+                     p.Cin, p.Cout);
+  return check_launch("first_wgrad_reduce_kernel");
+}
+
+}  // namespace unetdc

@@ -1,0 +1,98 @@
+// Parameter blocks and host launchers shared between the kernel files and the C-ABI layer.
+#pragma once
+#include "common.h"
+
+namespace unetdc {
+
+enum { MODE_STORE = 0, MODE_STATS = 1, MODE_AFFINE_RELU = 2, MODE_SHUFFLE = 3 };
+
+struct IgemmParams {
+  const void* x;
+  const void* w;
+  void* out;
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  float* stats;
+  int M, Ho, Wo, Hi, Wi, Cin, Cout, ldx, ldo, ntaps, stride, mode, shuf_c;
+  int mblocks, nblocks;
+  int offy[9];
+  int offx[9];
+};
+int launch_igemm(IgemmParams& p, int dtype, hipStream_t stream);
+int igemm_mblocks(long M, int Cout);
+
+struct WgradParams {
+  const void* a;
+  const void* b;
+  float* part;
+  int N, H, W, Hb, Wb, CI, CJ, lda, ldb, ntaps, stride;
+  int P;            // N*H*W
+  int chunk;        // pixels per K-slice (multiple of the block's pixel step)
+  int ksplit, itiles, jtiles;
+  int adv_y, adv_x; // pixel step decomposed: step = adv_y*W + adv_x
+  int offy[9];
+  int offx[9];
+};
+int launch_wgrad(WgradParams& p, float* out, void* workspace, long workspace_bytes, int dtype, hipStream_t stream);
+long wgrad_workspace_bytes(long P, int CI, int CJ, int ntaps, int dtype);
+
+struct FirstParams {
+  const float* x;        // [N][Cin][H][W] fp32
+  const float* w;        // [Cout][Cin][3][3] fp32 (PyTorch layout)
+  const float* bias;     // [Cout] or null
+  const float* scale;    // eval mode: y = relu(acc*scale + shift)
+  const float* shift;
+  void* y;               // [N*H*W][ldy] T
+  float* stats;          // [gridDim.x][2][Cout] or null
+  int N, H, W, Cin, Cout, ldy, dil;
+};
+struct FirstWgradParams {
+  const float* x;     // [N][Cin][H][W]
+  const void* dy;     // [P][lddy] T
+  float* part;        // [gridDim.x][Cin][9][Cout]
+  int N, H, W, Cin, Cout, lddy, dil;
+};
+int launch_first_fwd(FirstParams& p, int dtype, hipStream_t stream);
+int first_conv_mblocks(long P, int Cout);
+long first_wgrad_workspace_bytes(long P, int Cin, int Cout);
+int launch_first_wgrad(FirstWgradParams& p, float* dw, void* workspace, long workspace_bytes, int dtype,
+                       hipStream_t stream);
+
+struct ApplyParams {
+  const void* y; void* a; void* pooled;
+  const float* scale; const float* shift;
+  int N, H, W, C, ldy, lda, ldp;
+};
+struct BnBwdParams {
+  const void* dskip; const void* dpool; const void* y; void* dy;
+  const float* scale; const float* shift; const float* mean; const float* rstd;
+  const float* k1; const float* k2; const float* k3;
+  float* parts;            // [gridDim.x][3][C]
+  int N, H, W, C, lds, ldp, ldy, lddy;
+};
+struct HeadParams {
+  const void* a; const float* w; const float* b; float* probs;
+  const float* dprobs; void* da; float* parts;      // backward
+  int N, H, W, C, OC, lda, ldda;
+};
+int launch_bn_finalize(const float* parts, int nparts, long count, const float* gamma, const float* beta, float eps,
+                       float momentum, float* rm, float* rv, float* scale, float* shift, float* mean, float* rstd,
+                       int C, hipStream_t stream);
+int launch_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv,
+                          const float* conv_bias, float eps, float* scale, float* shift, int C, hipStream_t stream);
+int launch_apply(ApplyParams& p, int dtype, hipStream_t stream);
+long bn_bwd_workspace_bytes(int N, int H, int W, int C, int pooled, int dtype);
+int launch_bn_bwd(BnBwdParams& p, const float* gamma, float* dgamma, float* dbeta, float* dbias, void* workspace,
+                  long workspace_bytes, int dtype, hipStream_t stream);
+long head_bwd_workspace_bytes(int N, int H, int W, int C, int OC, int dtype);
+int launch_head_fwd(HeadParams& p, int dtype, hipStream_t stream);
+int launch_head_bwd(HeadParams& p, float* dw, float* db, void* workspace, long workspace_bytes, int dtype,
+                    hipStream_t stream);
+int launch_pack_conv3x3(const float* w, void* wf, void* wd, int Co, int Ci, int dtype, hipStream_t stream);
+int launch_pack_convT2x2(const float* w, void* wf, void* wd, int Ci, int Co, int dtype, hipStream_t stream);
+long channel_sum_workspace_bytes(long P, int C);
+int launch_channel_sum(const void* x, int ldx, float* out, void* workspace, long workspace_bytes, long P, int C,
+                       int dtype, hipStream_t stream);
+
+}  // namespace unetdc

@@ -1,0 +1,337 @@
+// Weight-gradient GEMM on the matrix cores: the reduction runs over PIXELS.
+//
+//   part[ks][t][i][j] = sum_{p in slice ks} A[p][i] * B[shift_t(p)][j]
+//
+//   conv3x3 wgrad  (autograd of nn.Conv2d, models/model_2.py:41-51):
+//       A = dY (i = cout), B = X shifted by (ky-1)*d,(kx-1)*d (j = cin)      -> dW[co][ci][ky][kx]
+//   ConvTranspose2d(2,2,s=2) wgrad (model_2.py:20-29):
+//       A = X  (i = cin),  B = dUp at (2y+a, 2x+b)            (j = cout)     -> dW[ci][co][a][b]
+//
+// Both operands are pixel-major (NHWC), i.e. K-major for this GEMM ("TN").  The MFMA wants each
+// lane to hold consecutive K for one row, so the LDS image stays [pixel][channel] exactly as it
+// arrives from HBM (coalesced 16-byte chunks) and
+//   * bf16: fragments are read with ds_read_b64_tr_b16 (hardware transpose, 4 pixels x 16
+//           channels per 16-lane group); the 64-byte units of a row are XOR-swizzled with the
+//           pixel index so the 4 pixel rows of one read hit 4 distinct bank windows;
+//   * fp32: v_mfma_f32_32x32x2_f32 takes one scalar per lane, read with ds_read_b32 from
+//           [pixel][channel] (32 consecutive channels per half-wave: conflict-free).
+// Tiles: 64x64 outputs per wave (2x2 MFMA 32x32).  Narrow layers (64 channels) use a 64x64 block
+// tile with the 4 waves splitting the pixel chunk (summed through LDS at the end); wide layers
+// use a 128x128 block tile (2x2 waves).  Across blocks the pixel range is split `ksplit` ways
+// into fp32 partial slabs that a second, deterministic kernel sums and permutes into PyTorch's
+// parameter layout -- no atomics, bitwise reproducible.
+#include "kernels.h"
+
+namespace unetdc {
+
+template <typename T, int TW> struct Frag;   // TW = tile width in units of 64 channels
+
+// ---- bf16: transposed LDS reads -----------------------------------------------------------------
+template <int TW> struct Frag<bf16_t, TW> {
+  static constexpr int RB = TW * 128;                     // bytes per pixel row in LDS
+  // byte offset (within an operand's stage image) of 16-byte chunk `ch` of pixel row `row`
+  __device__ static __forceinline__ int wr_off(int row, int ch) {
+    const int byte = ch * 16, unit = byte >> 6, within = byte & 63;
+    const int f = (TW == 1) ? ((row >> 1) & 1) : (row & 3);
+    return row * RB + ((unit ^ f) << 6) + within;
+  }
+  // per-lane base offset for the fragment of 32 channels starting at channel `cbase`,
+  // pixel rows kbase + 16*ks + [0,16): two tr reads (jj = 0,1) at +jj*4 rows.
+  __device__ static __forceinline__ int rd_off(int lane, int cbase, int krow0, int jj) {
+    const int i = lane & 15, G = (lane >> 4) & 3;
+    const int q = i >> 2, pp = i & 3, hi = G & 1, h = G >> 1;
+    const int krow = krow0 + 8 * h + 4 * jj + q;
+    const int byte = (cbase + 16 * hi + 4 * pp) * 2, unit = byte >> 6, within = byte & 63;
+    const int f = (TW == 1) ? ((krow >> 1) & 1) : (krow & 3);
+    return krow * RB + ((unit ^ f) << 6) + within;
+  }
+  // consume 16 pixels (one MFMA K-step)
+  __device__ static __forceinline__ void mma16(f32x16 (&acc)[2][2], const unsigned char* sa, const unsigned char* sb,
+                                               int lane, int ca, int cb, int krow0) {
+    bf16x8 fa[2], fb[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      s16x4 lo, hi;
+      lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(sa + rd_off(lane, ca + 32 * t, krow0, 0)));
+      hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(sa + rd_off(lane, ca + 32 * t, krow0, 1)));
+      fa[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(sb + rd_off(lane, cb + 32 * t, krow0, 0)));
+      hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(sb + rd_off(lane, cb + 32 * t, krow0, 1)));
+      fb[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+  }
+};
+
+// ---- fp32: scalar fragment reads ------------------------------------------------------------------
+template <int TW> struct Frag<float, TW> {
+  static constexpr int RB = TW * 256;
+  __device__ static __forceinline__ int wr_off(int row, int ch) { return row * RB + ch * 16; }
+  __device__ static __forceinline__ void mma16(f32x16 (&acc)[2][2], const unsigned char* sa, const unsigned char* sb,
+                                               int lane, int ca, int cb, int krow0) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int kp = 0; kp < 8; ++kp) {
+      const int krow = krow0 + 2 * kp + h;
+      float fa[2], fb[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        fa[t] = *reinterpret_cast<const float*>(sa + krow * RB + (ca + 32 * t + r) * 4);
+        fb[t] = *reinterpret_cast<const float*>(sb + krow * RB + (cb + 32 * t + r) * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+};
+
+// TW = 1: 64x64 block tile, the 4 waves split each pixel chunk; TW = 2: 128x128, waves 2x2.
+template <typename T, int TW>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
+  constexpr int RB = Frag<T, TW>::RB;                 // LDS bytes per pixel row (per operand)
+  constexpr int OPB = 16384;                          // LDS bytes per operand per stage
+  constexpr int BKP = OPB / RB;                       // pixels per block step
+  constexpr int CPR = RB / 16;                        // 16-byte chunks per pixel row
+  constexpr int RPP = 256 / CPR;                      // pixel rows staged per pass of the block
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int STAGE = 2 * OPB;
+  constexpr int WK = (TW == 1) ? BKP / 4 : BKP;       // pixels per wave per step
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per_slice = p.ntaps * p.itiles * p.jtiles;
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int ks = L / per_slice;
+  int rest = L - ks * per_slice;
+  const int t = rest / (p.itiles * p.jtiles);
+  rest -= t * p.itiles * p.jtiles;
+  const int it = rest / p.jtiles, jt = rest - it * p.jtiles;
+  const int i0 = it * TW * 64, j0 = jt * TW * 64;
+  const int oy = p.offy[t], ox = p.offx[t];
+
+  const T* __restrict__ ag = reinterpret_cast<const T*>(p.a);
+  const T* __restrict__ bg = reinterpret_cast<const T*>(p.b);
+
+  const long pbeg = (long)ks * p.chunk;
+  const long pend = (pbeg + p.chunk < (long)p.P) ? pbeg + p.chunk : (long)p.P;
+  const int nsteps = (int)((pend - pbeg + BKP - 1) / BKP);
+
+  // staging assignment: chunk c of pixel rows rr + RPP*i (i = 0..3)
+  const int c = tid % CPR, rr = tid / CPR;
+  int wr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) wr[i] = Frag<T, TW>::wr_off(rr + RPP * i, c);
+  // coordinates of the pixel this thread stages in row rr + RPP*i (advanced by BKP per step)
+  int cn[4], cy[4], cx[4];
+  const int HW = p.H * p.W;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long pp = pbeg + rr + RPP * i;
+    const int n = (int)(pp / HW), rem = (int)(pp - (long)n * HW);
+    cn[i] = n;
+    cy[i] = rem / p.W;
+    cx[i] = rem - cy[i] * p.W;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  u32x4 ra[4], rb[4];
+  long pcur = pbeg;      // first pixel of the step being loaded
+  auto gload = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long pp = pcur + rr + RPP * i;
+      const bool inr = pp < pend;
+      u32x4 va = {0u, 0u, 0u, 0u}, vb = {0u, 0u, 0u, 0u};
+      if (inr) {
+        va = ld16(ag + (pp * p.lda + i0 + c * EPC));
+        const int iy = cy[i] * p.stride + oy, ix = cx[i] * p.stride + ox;
+        if ((unsigned)iy < (unsigned)p.Hb && (unsigned)ix < (unsigned)p.Wb)
+          vb = ld16(bg + (((long)(cn[i] * p.Hb + iy) * p.Wb + ix) * p.ldb + j0 + c * EPC));
+      }
+      ra[i] = va;
+      rb[i] = vb;
+      // advance this row's pixel by BKP
+      cx[i] += p.adv_x;
+      if (cx[i] >= p.W) { cx[i] -= p.W; ++cy[i]; }
+      cy[i] += p.adv_y;
+      while (cy[i] >= p.H) { cy[i] -= p.H; ++cn[i]; }
+    }
+    pcur += BKP;
+  };
+  auto lds_store = [&](int stage) {
+    unsigned char* base = smem + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      st16(base + wr[i], ra[i]);
+      st16(base + OPB + wr[i], rb[i]);
+    }
+  };
+
+  const int wi = (TW == 1) ? 0 : (wave >> 1), wj = (TW == 1) ? 0 : (wave & 1);
+  const int kbase = (TW == 1) ? wave * WK : 0;
+
+  if (nsteps > 0) {
+    gload();
+    lds_store(0);
+  }
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const bool more = (s + 1 < nsteps);
+    if (more) gload();
+    const unsigned char* sa = smem + (s & 1) * STAGE;
+    const unsigned char* sb = sa + OPB;
+#pragma unroll
+    for (int k16 = 0; k16 < WK / 16; ++k16)
+      Frag<T, TW>::mma16(acc, sa, sb, lane, wi * 64, wj * 64, kbase + 16 * k16);
+    if (more) lds_store((s + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- write the partial slab --------------------------------------------------------------------
+  // acc[mi][nj][reg]: i = mi*32 + (reg&3) + 8*(reg>>2) + 4*h, j = nj*32 + (lane&31)
+  const int r = lane & 31, h = lane >> 5;
+  float* slab = p.part + ((long)ks * p.ntaps + t) * p.CI * p.CJ;
+  if (TW == 1) {
+    float* red = reinterpret_cast<float*>(smem);       // [wave][64][64] fp32 = 64 KB
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int i = mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h, j = nj * 32 + r;
+          red[(wave * 64 + i) * 64 + j] = acc[mi][nj][reg];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int idx = e * 256 + tid, i = idx >> 6, j = idx & 63;
+      const float v = red[idx] + red[4096 + idx] + red[8192 + idx] + red[12288 + idx];
+      slab[(long)(i0 + i) * p.CJ + j0 + j] = v;
+    }
+  } else {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int i = wi * 64 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h, j = wj * 64 + nj * 32 + r;
+          slab[(long)(i0 + i) * p.CJ + j0 + j] = acc[mi][nj][reg];
+        }
+  }
+}
+
+// out[(i*CJ + j)*ntaps + t] = sum_ks part[ks][t][i][j]   (PyTorch [Cout][Cin][3][3] / [Cin][Cout][2][2])
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int ksplit, int ntaps,
+                                    int CI, int CJ) {
+  const long ij = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = (long)CI * CJ;
+  if (ij >= n) return;
+  for (int t = 0; t < ntaps; ++t) {
+    float s = 0.f;
+    for (int ks = 0; ks < ksplit; ++ks) s += part[((long)ks * ntaps + t) * n + ij];
+    out[ij * ntaps + t] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+static int pixel_step(int dtype, bool wide) {
+  const int rb = (wide ? 2 : 1) * 64 * (dtype == UNETDC_BF16 ? 2 : 4);
+  return 16384 / rb;
+}
+
+static bool wgrad_wide(int CI, int CJ) { return CI % 128 == 0 && CJ % 128 == 0; }
+
+static void plan(long P, int CI, int CJ, int ntaps, int dtype, int& ksplit, int& chunk) {
+  const bool wide = wgrad_wide(CI, CJ);
+  const int step = pixel_step(dtype, wide);
+  const int tiles = ntaps * (CI / (wide ? 128 : 64)) * (CJ / (wide ? 128 : 64));
+  long want = (1024 + tiles - 1) / tiles;               // aim at ~4 workgroups per CU
+  const long maxsplit = (P + step - 1) / step;
+  if (want > maxsplit) want = maxsplit;
+  if (want < 1) want = 1;
+  long ch = (P + want - 1) / want;
+  ch = ((ch + step - 1) / step) * step;
+  chunk = (int)ch;
+  ksplit = (int)((P + ch - 1) / ch);
+}
+
+long wgrad_workspace_bytes(long P, int CI, int CJ, int ntaps, int dtype) {
+  int ksplit, chunk;
+  plan(P, CI, CJ, ntaps, dtype, ksplit, chunk);
+  return (long)ksplit * ntaps * CI * CJ * 4;
+}
+
+template <typename T, int TW>
+static int launch_w(WgradParams& p, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, TW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(wgrad_kernel) failed: %s", hipGetErrorString(e));
+      return UNETDC_ELAUNCH;
+    }
+    attr_done = true;
+  }
+  const long nwg = (long)p.ksplit * p.ntaps * p.itiles * p.jtiles;
+  hipLaunchKernelGGL((wgrad_kernel<T, TW>), dim3((unsigned)nwg), dim3(256), 65536, stream, p);
+  return check_launch("wgrad_kernel");
+}
+
+// Generic driver: fills partial slabs in `workspace` and reduces them into `out`.
+int launch_wgrad(WgradParams& p, float* out, void* workspace, long workspace_bytes, int dtype, hipStream_t stream) {
+  const int esz = dtype == UNETDC_BF16 ? 2 : 4;
+  UNETDC_REQUIRE(dtype == UNETDC_F32 || dtype == UNETDC_BF16, "wgrad: bad dtype %d", dtype);
+  UNETDC_REQUIRE(p.a && p.b && out && workspace, "wgrad: null pointer");
+  UNETDC_REQUIRE(p.CI % 64 == 0 && p.CJ % 64 == 0, "wgrad: channel counts (%d,%d) must be multiples of 64", p.CI, p.CJ);
+  UNETDC_REQUIRE(p.lda % (16 / esz) == 0 && p.ldb % (16 / esz) == 0, "wgrad: ld not 16-byte aligned");
+  UNETDC_REQUIRE(((uintptr_t)p.a % 16 == 0) && ((uintptr_t)p.b % 16 == 0), "wgrad: pointers must be 16-byte aligned");
+  const long P = (long)p.N * p.H * p.W;
+  UNETDC_REQUIRE(P > 0 && P < (1L << 31) - 4096, "wgrad: pixel count out of range");
+  p.P = (int)P;
+  const bool wide = wgrad_wide(p.CI, p.CJ);
+  plan(P, p.CI, p.CJ, p.ntaps, dtype, p.ksplit, p.chunk);
+  const long need = (long)p.ksplit * p.ntaps * p.CI * p.CJ * 4;
+  if (need > workspace_bytes) {
+    set_error("wgrad: workspace too small (%ld < %ld bytes)", workspace_bytes, need);
+    return UNETDC_EWORKSPACE;
+  }
+  p.part = reinterpret_cast<float*>(workspace);
+  p.itiles = p.CI / (wide ? 128 : 64);
+  p.jtiles = p.CJ / (wide ? 128 : 64);
+  const int step = pixel_step(dtype, wide);
+  p.adv_y = step / p.W;
+  p.adv_x = step % p.W;
+  int rc;
+  if (dtype == UNETDC_BF16)
+    rc = wide ? launch_w<bf16_t, 2>(p, stream) : launch_w<bf16_t, 1>(p, stream);
+  else
+    rc = wide ? launch_w<float, 2>(p, stream) : launch_w<float, 1>(p, stream);
+  if (rc != UNETDC_OK) return rc;
+  const long n = (long)p.CI * p.CJ;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p.part, out,
+                     p.ksplit, p.ntaps, p.CI, p.CJ);
+  return check_launch("wgrad_reduce_kernel");
+}
+
+}  // namespace unetdc

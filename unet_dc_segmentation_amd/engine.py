@@ -1,0 +1,412 @@
+"""Forward/backward schedule of the U-Net / U-Net-DC on the HIP kernels.
+
+PyTorch is plumbing here: device memory (caching allocator), the current stream, autograd's
+entry/exit points.  Every arithmetic op of ``UNetDC.forward`` (/root/reference/models/model_2.py:56-80)
+and of its autograd is one of the C-ABI calls in ``include/unetdc_hip.h``.
+
+Data layout in HBM
+------------------
+* activations: NHWC 2-D tensors ``[N*H*W, C]`` in the compute type (fp32 or bf16);
+* decoder concat (``torch.cat([up, skip], 1)``, model_2.py:68-77): ONE ``[pixels, 2C]`` buffer per
+  level -- the up-convolution writes columns ``[0, C)``, the encoder's normalise+ReLU pass writes
+  its skip into columns ``[C, 2C)``; the concat itself moves no bytes, and in backward the two halves
+  of the concat gradient are consumed in place (ConvT backward / encoder backward);
+* per conv stage the raw (pre-BatchNorm) output ``y`` is kept for backward; the activation
+  ``a = relu(scale*y + shift)`` is stored once (it is the next conv's input and the wgrad operand);
+* parameters stay fp32 ``nn.Parameter``s in PyTorch layout; K-contiguous packed copies in the
+  compute type are derived caches re-packed when a parameter's version counter changes;
+* gradients are written by the kernels straight into one flat fp32 buffer in ``parameters()``
+  order (so data-parallel buckets are contiguous slices, see dp.py).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import call
+
+ENCODER = ("enc1", "enc2", "enc3", "enc4")
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _Stage:
+    """One conv3x3 -> BatchNorm -> ReLU stage: parameters, packed weights, saved tensors."""
+
+    def __init__(self, eng, block, idx, cin, cout, dil, npix, hw, first=False):
+        m = getattr(eng.model, block)
+        self.name = f"{block}.{idx}"
+        self.conv, self.bn = m[idx], m[idx + 1]
+        self.cin, self.cout, self.dil, self.npix, self.hw, self.first = cin, cout, dil, npix, hw, first
+        dev, dt = eng.device, eng.tdtype
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.y = torch.empty(npix, cout, device=dev, dtype=dt)          # raw conv output (pre-BN)
+        if first:
+            rows = _lib.load().unetdc_conv3x3_first_stats_rows(npix, cout)
+        else:
+            rows = _lib.load().unetdc_conv3x3_stats_rows(npix, cout)
+            self.w_fwd = torch.empty(9 * cout * cin, device=dev, dtype=dt)
+            self.w_dgrad = torch.empty(9 * cout * cin, device=dev, dtype=dt)
+        self.stat_rows = rows
+        self.stats = torch.empty((rows + 64) * 2 * cout, **f32)
+        self.scale, self.shift = torch.empty(cout, **f32), torch.empty(cout, **f32)
+        self.mean, self.rstd = torch.empty(cout, **f32), torch.empty(cout, **f32)
+        self.packed_version = -1
+        self.x_in = None      # input view of the last forward (for wgrad)
+        self.a_out = None     # activated output view
+
+
+class UNetEngine:
+    def __init__(self, model, x):
+        _lib.load()
+        if not x.is_cuda:
+            raise _lib.UnetdcError("UNetEngine needs a HIP device tensor")
+        self.model = model
+        self.device = x.device
+        self.N, self.cin, self.H, self.W = x.shape
+        if self.H % 16 or self.W % 16:
+            raise ValueError(f"H and W must be multiples of 16 (4 poolings), got {self.H}x{self.W}")
+        if self.cin != model.in_channels:
+            raise ValueError(f"expected {model.in_channels} input channels, got {self.cin}")
+        self.dtype_name = model.compute_dtype
+        self.dt = _lib.BF16 if self.dtype_name == "bf16" else _lib.F32
+        self.tdtype = torch.bfloat16 if self.dtype_name == "bf16" else torch.float32
+        self.oc = model.out_channels
+        self._build()
+
+    # ------------------------------------------------------------------ construction
+    def matches(self, x):
+        return (x.device == self.device and tuple(x.shape) == (self.N, self.cin, self.H, self.W)
+                and self.dtype_name == self.model.compute_dtype)
+
+    def _build(self):
+        dev, dt = self.device, self.tdtype
+        N, H, W = self.N, self.H, self.W
+        widths = [64, 128, 256, 512, 1024]
+        self.res = [(H >> l, W >> l) for l in range(5)]
+        self.npix = [N * h * w for h, w in self.res]
+        d = self.model.DILATIONS
+        lib = _lib.load()
+        self.stages = {}
+        prev = self.cin
+        for l, name in enumerate(ENCODER + ("bottleneck",)):
+            c = widths[l]
+            self.stages[(name, 0)] = _Stage(self, name, 0, prev, c, d[name], self.npix[l], self.res[l],
+                                            first=(l == 0))
+            self.stages[(name, 3)] = _Stage(self, name, 3, c, c, d[name], self.npix[l], self.res[l])
+            prev = c
+        for lvl in (4, 3, 2, 1):
+            c = widths[lvl - 1]
+            name = f"dec{lvl}"
+            self.stages[(name, 0)] = _Stage(self, name, 0, 2 * c, c, d[name], self.npix[lvl - 1], self.res[lvl - 1])
+            self.stages[(name, 3)] = _Stage(self, name, 3, c, c, d[name], self.npix[lvl - 1], self.res[lvl - 1])
+        # activations
+        self.a0 = {}      # activated output of stage 0 of each block
+        self.a3 = {}      # activated output of stage 3 for bottleneck / decoder blocks
+        self.cat = {}     # concat buffers per level 1..4
+        self.pool = {}    # pooled encoder outputs per level 1..4
+        for l, name in enumerate(ENCODER):
+            c = widths[l]
+            self.a0[name] = torch.empty(self.npix[l], c, device=dev, dtype=dt)
+            self.cat[l + 1] = torch.empty(self.npix[l], 2 * c, device=dev, dtype=dt)
+            self.pool[l + 1] = torch.empty(self.npix[l + 1], c, device=dev, dtype=dt)
+        self.a0["bottleneck"] = torch.empty(self.npix[4], 1024, device=dev, dtype=dt)
+        self.a3["bottleneck"] = torch.empty(self.npix[4], 1024, device=dev, dtype=dt)
+        for lvl in (4, 3, 2, 1):
+            c = widths[lvl - 1]
+            self.a0[f"dec{lvl}"] = torch.empty(self.npix[lvl - 1], c, device=dev, dtype=dt)
+            self.a3[f"dec{lvl}"] = torch.empty(self.npix[lvl - 1], c, device=dev, dtype=dt)
+        # transposed convs: packed weights
+        self.up = {}
+        for lvl in (4, 3, 2, 1):
+            c = widths[lvl - 1]
+            self.up[lvl] = dict(mod=getattr(self.model, f"upconv{lvl}"), cin=2 * c, cout=c,
+                                w_fwd=torch.empty(4 * c * 2 * c, device=dev, dtype=dt),
+                                w_dgrad=torch.empty(4 * c * 2 * c, device=dev, dtype=dt), version=-1)
+        # gradient-side buffers (allocated lazily on the first backward)
+        self.grad_bufs = None
+        # parameter order == model.parameters() order; flat gradient offsets
+        self.params = list(self.model.parameters())
+        self.pindex = {id(p): i for i, p in enumerate(self.params)}
+        offs, o = [], 0
+        for p in self.params:
+            offs.append(o)
+            o += p.numel()
+        self.poffs, self.nparams = offs, o
+        # workspace: the largest request of any backward op
+        need = 1 << 20
+        for (name, idx), st in self.stages.items():
+            h, w = st.hw
+            if st.first:
+                need = max(need, lib.unetdc_conv3x3_first_wgrad_workspace(N, h, w, st.cin, st.cout))
+            else:
+                need = max(need, lib.unetdc_conv3x3_wgrad_workspace(N, h, w, st.cin, st.cout, self.dt))
+            need = max(need, lib.unetdc_bn_relu_bwd_workspace(N, h, w, st.cout, 0, self.dt))
+            need = max(need, lib.unetdc_bn_relu_bwd_workspace(N, h, w, st.cout, 1, self.dt))
+        for lvl, u in self.up.items():
+            h, w = self.res[lvl]
+            need = max(need, lib.unetdc_convT2x2_wgrad_workspace(N, h, w, u["cin"], u["cout"], self.dt))
+            need = max(need, lib.unetdc_channel_sum_workspace(self.npix[lvl - 1], u["cout"]))
+        need = max(need, lib.unetdc_head_bwd_workspace(N, H, W, 64, self.oc, self.dt))
+        self.ws_bytes = int(need)
+        self.workspace = None
+        self.probs = None
+        self.x_saved = None
+
+    # ------------------------------------------------------------------ weight caches
+    def _pack(self, need_dgrad):
+        s = _stream()
+        for st in self.stages.values():
+            if st.first:
+                continue
+            w = st.conv.weight
+            if st.packed_version != w._version or (need_dgrad and not getattr(st, "has_dgrad", False)):
+                call("unetdc_pack_conv3x3", w.data_ptr(), st.w_fwd.data_ptr(),
+                     st.w_dgrad.data_ptr() if need_dgrad else None, st.cout, st.cin, self.dt, s)
+                st.packed_version = w._version
+                st.has_dgrad = need_dgrad
+        for u in self.up.values():
+            w = u["mod"].weight
+            if u["version"] != w._version or (need_dgrad and not u.get("has_dgrad", False)):
+                call("unetdc_pack_convT2x2", w.data_ptr(), u["w_fwd"].data_ptr(),
+                     u["w_dgrad"].data_ptr() if need_dgrad else None, u["cin"], u["cout"], self.dt, s)
+                u["version"] = w._version
+                u["has_dgrad"] = need_dgrad
+
+    # ------------------------------------------------------------------ forward
+    def run(self, x):
+        """Called by the nn.Module: returns probabilities [N, OC, H, W] fp32 (autograd aware)."""
+        model = self.model
+        if x.dtype != torch.float32:
+            x = x.float()
+        x = x.contiguous()
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.params)
+        if model.training and not needs_grad:
+            # train-mode BatchNorm under no_grad: same arithmetic, nothing saved
+            return self.forward(x, train=True)
+        if not model.training and needs_grad:
+            raise _lib.UnetdcError("autograd through eval-mode BatchNorm is not implemented in the HIP path; "
+                                   "call under torch.no_grad() or switch to train()")
+        if needs_grad:
+            return _UNetFunction.apply(x, self, *self.params)
+        return self.forward(x, train=False)
+
+    def _stage_fwd(self, st, xin, dst, train, pooled=None):
+        """conv -> BN -> ReLU.  xin: [npix, cin] view (or the NCHW image for the first stage);
+        dst: [npix, cout] view receiving the activation; pooled: optional [npix/4, cout] view."""
+        s = _stream()
+        N = self.N
+        h, w = st.hw
+        conv, bn = st.conv, st.bn
+        st.x_in, st.a_out = xin, dst
+        if train:
+            y = st.y
+            if st.first:
+                call("unetdc_conv3x3_first_fwd", xin.data_ptr(), conv.weight.data_ptr(), conv.bias.data_ptr(),
+                     None, None, y.data_ptr(), y.stride(0), st.stats.data_ptr(), N, h, w, st.cin, st.cout,
+                     st.dil, self.dt, s)
+            else:
+                call("unetdc_conv3x3_fwd", xin.data_ptr(), xin.stride(0), st.w_fwd.data_ptr(), conv.bias.data_ptr(),
+                     None, None, y.data_ptr(), y.stride(0), st.stats.data_ptr(), N, h, w, st.cin, st.cout,
+                     st.dil, self.dt, s)
+            track = bn.track_running_stats and bn.running_mean is not None
+            mom = BN_MOMENTUM if bn.momentum is None else bn.momentum
+            call("unetdc_bn_finalize", st.stats.data_ptr(), st.stat_rows, st.npix, bn.weight.data_ptr(),
+                 bn.bias.data_ptr(), bn.eps, mom, _ptr(bn.running_mean) if track else None,
+                 _ptr(bn.running_var) if track else None, st.scale.data_ptr(), st.shift.data_ptr(),
+                 st.mean.data_ptr(), st.rstd.data_ptr(), st.cout, s)
+            if track:
+                bn.num_batches_tracked += 1
+            call("unetdc_bn_relu_apply", y.data_ptr(), y.stride(0), st.scale.data_ptr(), st.shift.data_ptr(),
+                 dst.data_ptr(), dst.stride(0), _ptr(pooled), pooled.stride(0) if pooled is not None else 0,
+                 N, h, w, st.cout, self.dt, s)
+        else:
+            call("unetdc_bn_eval_affine", bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                 bn.running_var.data_ptr(), conv.bias.data_ptr(), bn.eps, st.scale.data_ptr(), st.shift.data_ptr(),
+                 st.cout, s)
+            if st.first:
+                call("unetdc_conv3x3_first_fwd", xin.data_ptr(), conv.weight.data_ptr(), None, st.scale.data_ptr(),
+                     st.shift.data_ptr(), dst.data_ptr(), dst.stride(0), None, N, h, w, st.cin, st.cout, st.dil,
+                     self.dt, s)
+            else:
+                call("unetdc_conv3x3_fwd", xin.data_ptr(), xin.stride(0), st.w_fwd.data_ptr(), None,
+                     st.scale.data_ptr(), st.shift.data_ptr(), dst.data_ptr(), dst.stride(0), None, N, h, w,
+                     st.cin, st.cout, st.dil, self.dt, s)
+            if pooled is not None:
+                call("unetdc_bn_relu_apply", dst.data_ptr(), dst.stride(0), None, None, None, 0,
+                     pooled.data_ptr(), pooled.stride(0), N, h, w, st.cout, self.dt, s)
+
+    def forward(self, x, train):
+        self._pack(need_dgrad=train)
+        s = _stream()
+        N = self.N
+        widths = [64, 128, 256, 512, 1024]
+        hin = x
+        for l, name in enumerate(ENCODER):
+            c = widths[l]
+            self._stage_fwd(self.stages[(name, 0)], hin, self.a0[name], train)
+            skip = self.cat[l + 1][:, c:]
+            self._stage_fwd(self.stages[(name, 3)], self.a0[name], skip, train, pooled=self.pool[l + 1])
+            hin = self.pool[l + 1]
+        self._stage_fwd(self.stages[("bottleneck", 0)], hin, self.a0["bottleneck"], train)
+        self._stage_fwd(self.stages[("bottleneck", 3)], self.a0["bottleneck"], self.a3["bottleneck"], train)
+        hin = self.a3["bottleneck"]
+        for lvl in (4, 3, 2, 1):
+            u = self.up[lvl]
+            c = u["cout"]
+            h, w = self.res[lvl]                               # input resolution of the up-conv
+            upv = self.cat[lvl][:, :c]
+            u["x_in"] = hin
+            call("unetdc_convT2x2_fwd", hin.data_ptr(), hin.stride(0), u["w_fwd"].data_ptr(),
+                 u["mod"].bias.data_ptr(), upv.data_ptr(), upv.stride(0), N, h, w, u["cin"], c, self.dt, s)
+            name = f"dec{lvl}"
+            self._stage_fwd(self.stages[(name, 0)], self.cat[lvl], self.a0[name], train)
+            self._stage_fwd(self.stages[(name, 3)], self.a0[name], self.a3[name], train)
+            hin = self.a3[name]
+        probs = torch.empty(N, self.oc, self.H, self.W, device=self.device, dtype=torch.float32)
+        oc = self.model.out_conv
+        call("unetdc_head_fwd", hin.data_ptr(), hin.stride(0), oc.weight.data_ptr(), oc.bias.data_ptr(),
+             probs.data_ptr(), N, self.H, self.W, 64, self.oc, self.dt, s)
+        self.head_in = hin
+        return probs
+
+    # ------------------------------------------------------------------ backward
+    def _ensure_grad_bufs(self):
+        if self.grad_bufs is not None:
+            return
+        dev, dt = self.device, self.tdtype
+        g = {}
+        widths = [64, 128, 256, 512, 1024]
+        for l in range(5):
+            c = widths[l]
+            g[("dy", l)] = torch.empty(self.npix[l], c, device=dev, dtype=dt)       # grad of a conv output
+            g[("da", l)] = torch.empty(self.npix[l], c, device=dev, dtype=dt)       # grad of an activation
+            if l < 4:
+                g[("dcat", l + 1)] = torch.empty(self.npix[l], 2 * c, device=dev, dtype=dt)
+                g[("dpool", l + 1)] = torch.empty(self.npix[l + 1], c, device=dev, dtype=dt)
+        self.grad_bufs = g
+        self.workspace = torch.empty(self.ws_bytes, device=dev, dtype=torch.uint8)
+
+    def _gview(self, flat, p):
+        i = self.pindex[id(p)]
+        return flat[self.poffs[i]: self.poffs[i] + p.numel()]
+
+    def _stage_bwd(self, st, flat, lvl, dskip, dpool, dx_out):
+        """Backward of one stage.  dskip/dpool: incoming gradient(s) of the activation;
+        dx_out: [npix, cin] view to receive the input gradient (None for the first stage)."""
+        s = _stream()
+        N = self.N
+        h, w = st.hw
+        g = self.grad_bufs
+        dy = g[("dy", lvl)]
+        ws, wsb = self.workspace.data_ptr(), self.ws_bytes
+        call("unetdc_bn_relu_bwd", _ptr(dskip), dskip.stride(0) if dskip is not None else 0,
+             _ptr(dpool), dpool.stride(0) if dpool is not None else 0, st.y.data_ptr(), st.y.stride(0),
+             st.scale.data_ptr(), st.shift.data_ptr(), st.mean.data_ptr(), st.rstd.data_ptr(),
+             st.bn.weight.data_ptr(), dy.data_ptr(), dy.stride(0), self._gview(flat, st.bn.weight).data_ptr(),
+             self._gview(flat, st.bn.bias).data_ptr(), self._gview(flat, st.conv.bias).data_ptr(), ws, wsb,
+             N, h, w, st.cout, self.dt, s)
+        dw = self._gview(flat, st.conv.weight)
+        xin = st.x_in
+        if st.first:
+            call("unetdc_conv3x3_first_wgrad", xin.data_ptr(), dy.data_ptr(), dy.stride(0), dw.data_ptr(), ws, wsb,
+                 N, h, w, st.cin, st.cout, st.dil, self.dt, s)
+        else:
+            call("unetdc_conv3x3_wgrad", xin.data_ptr(), xin.stride(0), dy.data_ptr(), dy.stride(0), dw.data_ptr(),
+                 ws, wsb, N, h, w, st.cin, st.cout, st.dil, self.dt, s)
+            if dx_out is not None:
+                call("unetdc_conv3x3_dgrad", dy.data_ptr(), dy.stride(0), st.w_dgrad.data_ptr(), dx_out.data_ptr(),
+                     dx_out.stride(0), N, h, w, st.cin, st.cout, st.dil, self.dt, s)
+
+    def _block_bwd(self, name, flat, lvl, dskip, dpool, dx_out):
+        """stage 3 then stage 0 of a block; the gradient between them lives in the 'da' buffer."""
+        da = self.grad_bufs[("da", lvl)]
+        self._stage_bwd(self.stages[(name, 3)], flat, lvl, dskip, dpool, da)
+        self._stage_bwd(self.stages[(name, 0)], flat, lvl, da, None, dx_out)
+        self._notify(flat, name)
+
+    def _notify(self, flat, name):
+        hook = self.model.grad_ready_hook
+        if hook is not None:
+            mod = getattr(self.model, name)
+            ps = list(mod.parameters())
+            lo = self.poffs[self.pindex[id(ps[0])]]
+            hi = self.poffs[self.pindex[id(ps[-1])]] + ps[-1].numel()
+            hook(flat, lo, hi)
+
+    def backward(self, dprobs):
+        """dprobs: [N, OC, H, W] fp32.  Returns the flat fp32 gradient buffer (parameters() order)."""
+        self._ensure_grad_bufs()
+        s = _stream()
+        N = self.N
+        g = self.grad_bufs
+        ws, wsb = self.workspace.data_ptr(), self.ws_bytes
+        flat = torch.empty(self.nparams, device=self.device, dtype=torch.float32)
+        dprobs = dprobs.contiguous()
+        oc = self.model.out_conv
+        da = g[("da", 0)]
+        call("unetdc_head_bwd", dprobs.data_ptr(), self.probs.data_ptr(), self.head_in.data_ptr(),
+             self.head_in.stride(0), oc.weight.data_ptr(), da.data_ptr(), da.stride(0),
+             self._gview(flat, oc.weight).data_ptr(), self._gview(flat, oc.bias).data_ptr(), ws, wsb,
+             N, self.H, self.W, 64, self.oc, self.dt, s)
+        self._notify(flat, "out_conv")
+        # decoder, level 1 (full resolution) up to level 4
+        dact = da                               # gradient of the current block's activated output
+        for lvl in (1, 2, 3, 4):
+            l = lvl - 1
+            u = self.up[lvl]
+            c = u["cout"]
+            dcat = g[("dcat", lvl)]
+            self._block_bwd(f"dec{lvl}", flat, l, dact, None, dcat)
+            dup = dcat[:, :c]
+            h, w = self.res[lvl]
+            xin = u["x_in"]
+            call("unetdc_convT2x2_wgrad", xin.data_ptr(), xin.stride(0), dup.data_ptr(), dup.stride(0),
+                 self._gview(flat, u["mod"].weight).data_ptr(), ws, wsb, N, h, w, u["cin"], c, self.dt, s)
+            call("unetdc_channel_sum", dup.data_ptr(), dup.stride(0), self._gview(flat, u["mod"].bias).data_ptr(),
+                 ws, wsb, self.npix[l], c, self.dt, s)
+            dnext = g[("da", lvl)]               # gradient w.r.t. the up-conv input (level lvl+1 resolution)
+            call("unetdc_convT2x2_dgrad", dup.data_ptr(), dup.stride(0), u["w_dgrad"].data_ptr(), dnext.data_ptr(),
+                 dnext.stride(0), N, h, w, u["cin"], c, self.dt, s)
+            self._notify(flat, f"upconv{lvl}")
+            dact = dnext
+        # bottleneck: input is pool[4]
+        self._block_bwd("bottleneck", flat, 4, dact, None, g[("dpool", 4)])
+        # encoder, level 4 down to 1: gradient = skip half of dcat + scatter of the pooled gradient
+        for lvl in (4, 3, 2, 1):
+            l = lvl - 1
+            c = [64, 128, 256, 512][l]
+            name = ENCODER[l]
+            dskip = g[("dcat", lvl)][:, c:]
+            dx_out = g[("dpool", lvl - 1)] if lvl > 1 else None
+            self._block_bwd(name, flat, l, dskip, g[("dpool", lvl)], dx_out)
+        return flat
+
+
+class _UNetFunction(torch.autograd.Function):
+    """Autograd boundary: one node for the whole network (forward kernels / backward kernels)."""
+
+    @staticmethod
+    def forward(ctx, x, engine, *params):
+        probs = engine.forward(x, train=True)
+        engine.probs = probs
+        engine.x_saved = x
+        ctx.engine = engine
+        return probs
+
+    @staticmethod
+    def backward(ctx, dprobs):
+        eng = ctx.engine
+        flat = eng.backward(dprobs)
+        grads = []
+        for p, o in zip(eng.params, eng.poffs):
+            grads.append(flat[o:o + p.numel()].view_as(p) if p.requires_grad else None)
+        return (None, None, *grads)
