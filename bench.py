@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of one U-Net-DC training step (forward + Focal/Dice loss +
+backward, plus the Adam step and -- for N > 1 -- the RCCL gradient all-reduce), 512x512x1,
+batch 8 per GPU, bf16 storage / fp32 accumulate (BASELINE.json metric, configs[2]).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  Besides the contract fields it carries
+  roofline     -- the dominant kernel (bf16 implicit-GEMM conv): algorithmic dense FLOPs per launch /
+                  average launch time measured live with HIP events on the launch stream over the
+                  timed steps, against the 2.5 PFLOP/s dense bf16 MFMA peak;
+  cpu_baseline -- the CPU port of the reference path (oracle/unetdc_torch_cpu.py, the same ATen ops
+                  the reference calls) timed on this host's cores on a bounded sample (N = 1 only).
+Everything inside the timed region is real work: no step is skipped, the optimizer step and the
+weight re-packing it triggers are included; the reference loop's per-step .item()/.cpu() syncs
+(train_DC_focal.py:257-269) are not part of the metric and are excluded.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def synthetic_batch(seed, n, h, w, cin=1, discs=200):
+    """U[0,1) noise + `discs` bright discs per image ("droplets"); target = disc mask."""
+    rng = np.random.default_rng(seed)
+    x = rng.random((n, cin, h, w), dtype=np.float32) * 0.6
+    t = np.zeros((n, 1, h, w), dtype=np.float32)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for i in range(n):
+        cy, cx = rng.integers(0, h, discs), rng.integers(0, w, discs)
+        rad = rng.uniform(1, 12, discs)
+        for k in range(discs):
+            r = int(rad[k]) + 1
+            y0, y1, x0, x1 = max(cy[k] - r, 0), min(cy[k] + r + 1, h), max(cx[k] - r, 0), min(cx[k] + r + 1, w)
+            m = (yy[y0:y1, x0:x1] - cy[k]) ** 2 + (xx[y0:y1, x0:x1] - cx[k]) ** 2 <= rad[k] ** 2
+            t[i, 0, y0:y1, x0:x1][m] = 1.0
+    x += 0.4 * t
+    return torch.from_numpy(x), torch.from_numpy(t)
+
+
+def igemm_flops(name, a):
+    """Nominal dense FLOPs (padded taps included) of one implicit-GEMM launch from its C-ABI args."""
+    if name == "unetdc_conv3x3_fwd":
+        n, h, w, cin, cout = a[9:14]
+        return 2.0 * n * h * w * cout * cin * 9, cout
+    if name == "unetdc_conv3x3_dgrad":
+        n, h, w, cin, cout = a[5:10]
+        return 2.0 * n * h * w * cout * cin * 9, cin
+    if name == "unetdc_convT2x2_fwd":
+        n, h, w, cin, cout = a[6:11]
+        return 2.0 * n * h * w * cin * 4 * cout, 4 * cout
+    if name == "unetdc_convT2x2_dgrad":
+        n, h, w, cin, cout = a[5:10]
+        return 2.0 * n * h * w * cin * 4 * cout, cin
+    raise KeyError(name)
+
+
+def host_cores():
+    """Cores this process may actually use: cgroup quota if there is one, else the affinity mask,
+    capped at 16 (the CPU share of a one-GPU box; os.cpu_count() reports the whole host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("UNETDC_BENCH_CPU_CORES", "16"))))
+
+
+def cpu_baseline(batch, h, w, cin):
+    """CPU port of the reference path: forward + focal/dice loss + backward on the host cores."""
+    from oracle import unetdc_torch_cpu as otc
+    from models.model_2 import UNetDC
+    torch.manual_seed(0)
+    model = UNetDC(in_channels=cin, out_channels=1)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    xw, tw = synthetic_batch(99, 1, h, w, cin, discs=20)
+    otc.train_step_grads(xw, tw, sd, dict(model.DILATIONS))          # warm-up (oneDNN primitive caches)
+    x, t = synthetic_batch(100, batch, h, w, cin, discs=50)
+    t0 = time.perf_counter()
+    otc.train_step_grads(x, t, sd, dict(model.DILATIONS))
+    dt = time.perf_counter() - t0
+    return {"value": batch / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 fwd+loss+bwd step of bs={batch} {h}x{w}x{cin} fp32 on PyTorch-CPU "
+                      f"(oracle/unetdc_torch_cpu.py) after a bs=1 warm-up; {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--in-channels", type=int, default=1)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--arch", default="unetdc", choices=["unetdc", "unet"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    args = ap.parse_args()
+
+    from unet_dc_segmentation_amd import _lib, dp as dpmod
+    from utils.metrics_DC import focal_dice_loss
+    rank, local, world = dpmod.init_from_env("nccl")
+    if world != args.gpus and rank == 0:
+        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+
+    if args.arch == "unetdc":
+        from models.model_2 import UNetDC as Net
+    else:
+        from models.model import UNet as Net
+    torch.manual_seed(0)                                   # identical replicas
+    model = Net(in_channels=args.in_channels, out_channels=1).to(dev).train()
+    model.set_compute_dtype(args.dtype)
+    wrapper = dpmod.DataParallel(model) if world > 1 else None
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)     # train_DC_focal.py:224
+    x, t = synthetic_batch(1000 + rank, args.batch, args.size, args.size, args.in_channels)
+    x, t = x.to(dev), t.to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        p = model(x)
+        loss = focal_dice_loss(p, t, alpha=1.0, gamma=2.0, ratio=0.3)      # train_DC_focal.py:222
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    igemm_calls = ["unetdc_conv3x3_fwd", "unetdc_conv3x3_dgrad", "unetdc_convT2x2_fwd", "unetdc_convT2x2_dgrad"]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    _lib.start_timing(igemm_calls)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    records = _lib.stop_timing()
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel -------------------------------------------------
+        groups = {}
+        for name, a, ms in records:
+            fl, ncols = igemm_flops(name, a)
+            key = "igemm_conv_kernel<%s,2,2>" % args.dtype if ncols % 128 == 0 else "igemm_conv_kernel<%s,4,1>" % args.dtype
+            gsum = groups.setdefault(key, [0.0, 0.0, 0])
+            gsum[0] += fl
+            gsum[1] += ms
+            gsum[2] += 1
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        kernels = []
+        for key, (fl, ms, cnt) in groups.items():
+            kernels.append({"kernel": key, "launches_per_step": cnt / args.steps, "avg_launch_ms": ms / cnt,
+                            "gflop_per_launch": fl / cnt / 1e9, "tflops": fl / (ms * 1e-3) / 1e12,
+                            "ms_per_step": ms / args.steps})
+        kernels.sort(key=lambda k: -k["ms_per_step"])
+        dom = kernels[0]
+        roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak,
+                    "unit": "TFLOP/s", "frac": dom["tflops"] / peak, "traffic": None,
+                    "flop_per_launch": dom["gflop_per_launch"] * 1e9, "avg_launch_ms": dom["avg_launch_ms"],
+                    "launches_per_step": dom["launches_per_step"], "all_igemm_kernels": kernels}
+        nominal_gflop_img = 1153.9 if (args.size == 512 and args.in_channels == 1) else None
+        imgs = args.batch * world * args.steps
+        out = {
+            "metric": "images/sec fwd+bwd, 512x512x1 U-Net-DC, bs=8/GPU",
+            "value": imgs / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"train step (fwd + Focal/Dice loss + bwd + Adam{' + RCCL grad all-reduce' if world > 1 else ''}) "
+                                   f"{args.arch} bs={args.batch}/GPU {args.size}x{args.size}x{args.in_channels} "
+                                   "(BASELINE configs[2]/[3])",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "timed_region": "zero_grad, model(x), focal_dice_loss, backward, all-reduce, Adam step, weight re-pack"},
+            "roofline": roofline,
+            "final_loss": final_loss,
+        }
+        if nominal_gflop_img:
+            out["whole_step_tflops_nominal"] = nominal_gflop_img * 1e9 * imgs / elapsed / 1e12
+        if wrapper is not None:
+            out["allreduce_buckets_per_step"] = wrapper.stats["buckets"] / (args.steps + args.warmup)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.size, args.size, args.in_channels)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

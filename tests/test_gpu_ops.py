@@ -119,8 +119,9 @@ def test_first_conv(dtype, cin):
     np.testing.assert_allclose(stc[1].numpy(), (y.double() ** 2).sum(dim=(0, 2, 3)).numpy(), rtol=1e-4, atol=1e-2)
     # eval epilogue
     sc, sh = (torch.rand(cout, generator=g) + 0.5), torch.randn(cout, generator=g)
+    scd, shd = sc.cuda(), sh.cuda()          # keep the device tensors alive across the call
     y2v = G.empty_nhwc(n * h * w, cout, dtype)
-    call("unetdc_conv3x3_first_fwd", xd.data_ptr(), wdv.data_ptr(), None, sc.cuda().data_ptr(), sh.cuda().data_ptr(),
+    call("unetdc_conv3x3_first_fwd", xd.data_ptr(), wdv.data_ptr(), None, scd.data_ptr(), shd.data_ptr(),
          y2v.data_ptr(), y2v.stride(0), None, n, h, w, cin, cout, d, G.DT[dtype], G.stream())
     y2_ref = torch.relu(F.conv2d(x, wt, None, padding=d) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
     assert rel(G.from_nhwc(y2v, n, h, w), y2_ref) < (2e-6 if dtype == "f32" else 4e-3)
@@ -149,7 +150,8 @@ def test_conv_transpose(dtype, case):
     wf, wd = G.pack_convT(wt, dtype)
     xv = G.to_nhwc(x, dtype)
     upv = G.empty_nhwc(n * 4 * h * w, cout, dtype, ld=2 * cout, off=0)       # first half of a concat buffer
-    call("unetdc_convT2x2_fwd", xv.data_ptr(), xv.stride(0), wf.data_ptr(), b.cuda().data_ptr(), upv.data_ptr(),
+    bdev = b.cuda()
+    call("unetdc_convT2x2_fwd", xv.data_ptr(), xv.stride(0), wf.data_ptr(), bdev.data_ptr(), upv.data_ptr(),
          upv.stride(0), n, h, w, cin, cout, G.DT[dtype], G.stream())
     assert rel(G.from_nhwc(upv, n, 2 * h, 2 * w), y_ref.detach()) < TOL[dtype]
     dupv = G.to_nhwc(dup, dtype, ld=2 * cout, off=0)

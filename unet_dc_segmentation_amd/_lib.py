@@ -82,5 +82,34 @@ def check(rc, what=""):
         raise UnetdcError(f"{what or 'unetdc'} failed (code {rc}): {msg}")
 
 
+# ---- optional per-call timing (bench.py's roofline leg): HIP events recorded on the stream the
+# kernels are launched on (PyTorch's current stream), bracketing selected C-ABI calls.
+_timing = None
+
+
+def start_timing(names):
+    global _timing
+    _timing = {"names": set(names), "records": []}
+
+
+def stop_timing():
+    """Returns [(name, args, milliseconds)] for every bracketed call since start_timing()."""
+    global _timing
+    t, _timing = _timing, None
+    if t is None:
+        return []
+    torch.cuda.synchronize()
+    return [(n, a, e0.elapsed_time(e1)) for n, a, e0, e1 in t["records"]]
+
+
 def call(name, *args):
+    t = _timing
+    if t is not None and name in t["names"]:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(load(), name)(*args)
+        e1.record()
+        t["records"].append((name, args, e0, e1))
+        check(rc, name)
+        return
     check(getattr(load(), name)(*args), name)

@@ -46,6 +46,11 @@ template <> struct Elem<bf16_t> {
   static constexpr int BYTES = 2;
 };
 
+// NOTE: never write __builtin_bit_cast(float, vec[i]) on an ext_vector element reached through a
+// reference -- hipcc (ROCm 7.2) folds every i to element 0.  Go through a scalar first.
+__device__ __forceinline__ float bits_f32(unsigned int u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ unsigned int f32_bits(float f) { return __builtin_bit_cast(unsigned int, f); }
+
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
@@ -61,12 +66,15 @@ template <> struct Chunk<float> {
   static constexpr int N = 4;
   __device__ static void unpack(const u32x4& c, float* f) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) f[i] = __builtin_bit_cast(float, c[i]);
+    for (int i = 0; i < 4; ++i) {
+      const unsigned int u = c[i];
+      f[i] = bits_f32(u);
+    }
   }
   __device__ static u32x4 pack(const float* f) {
     u32x4 c;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) c[i] = __builtin_bit_cast(unsigned int, f[i]);
+    for (int i = 0; i < 4; ++i) c[i] = f32_bits(f[i]);
     return c;
   }
 };
@@ -75,8 +83,9 @@ template <> struct Chunk<bf16_t> {
   __device__ static void unpack(const u32x4& c, float* f) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      f[2 * i] = __builtin_bit_cast(float, c[i] << 16);
-      f[2 * i + 1] = __builtin_bit_cast(float, c[i] & 0xffff0000u);
+      const unsigned int u = c[i];
+      f[2 * i] = bits_f32(u << 16);
+      f[2 * i + 1] = bits_f32(u & 0xffff0000u);
     }
   }
   __device__ static u32x4 pack(const float* f) {

@@ -40,9 +40,10 @@ template <> struct Mma<bf16_t> {
 template <> struct Mma<float> {
   __device__ static __forceinline__ void run(f32x16& acc, const u32x4& a, const u32x4& b) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a[s]), __builtin_bit_cast(float, b[s]),
-                                                 acc, 0, 0, 0);
+    for (int s = 0; s < 4; ++s) {
+      const unsigned int ua = a[s], ub = b[s];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bits_f32(ua), bits_f32(ub), acc, 0, 0, 0);
+    }
   }
 };
 

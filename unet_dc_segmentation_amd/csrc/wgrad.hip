@@ -241,16 +241,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 }
 
 // out[(i*CJ + j)*ntaps + t] = sum_ks part[ks][t][i][j]   (PyTorch [Cout][Cin][3][3] / [Cin][Cout][2][2])
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int ksplit, int ntaps,
-                                    int CI, int CJ) {
-  const long ij = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// one thread per (t, ij): reads coalesced over ij, four independent partial sums for memory-level
+// parallelism; the summation order is fixed, so the result is bitwise reproducible.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                           int ksplit, int ntaps, int CI, int CJ) {
   const long n = (long)CI * CJ;
-  if (ij >= n) return;
-  for (int t = 0; t < ntaps; ++t) {
-    float s = 0.f;
-    for (int ks = 0; ks < ksplit; ++ks) s += part[((long)ks * ntaps + t) * n + ij];
-    out[ij * ntaps + t] = s;
+  const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n * ntaps) return;
+  const int t = (int)(g / n);
+  const long ij = g - (long)t * n;
+  const float* src = part + (long)t * n + ij;
+  const long stride = (long)ntaps * n;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int ks = 0;
+  for (; ks + 4 <= ksplit; ks += 4) {
+    s0 += src[(long)ks * stride];
+    s1 += src[(long)(ks + 1) * stride];
+    s2 += src[(long)(ks + 2) * stride];
+    s3 += src[(long)(ks + 3) * stride];
   }
+  for (; ks < ksplit; ++ks) s0 += src[(long)ks * stride];
+  out[ij * ntaps + t] = (s0 + s1) + (s2 + s3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -328,7 +339,7 @@ int launch_wgrad(WgradParams& p, float* out, void* workspace, long workspace_byt
   else
     rc = wide ? launch_w<float, 2>(p, stream) : launch_w<float, 1>(p, stream);
   if (rc != UNETDC_OK) return rc;
-  const long n = (long)p.CI * p.CJ;
+  const long n = (long)p.CI * p.CJ * p.ntaps;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p.part, out,
                      p.ksplit, p.ntaps, p.CI, p.CJ);
   return check_launch("wgrad_reduce_kernel");

@@ -1,0 +1,121 @@
+"""Data-parallel training: one process per GPU, gradients all-reduced with RCCL over xGMI,
+overlapped with the backward pass.
+
+The reference is single-device (train_DC_focal.py:208); this is the new exchange step that
+BASELINE config 3 asks for.  Semantics = DistributedDataParallel defaults:
+replicated parameters (rank 0 broadcast at start), per-rank BatchNorm statistics (the reference uses
+plain BatchNorm2d, models/model_2.py:45,52, no SyncBN), gradients averaged over ranks.
+
+Mechanics: the HIP backward (engine.py) writes all gradients into ONE flat fp32 buffer in
+``parameters()`` order and calls ``grad_ready_hook(flat, lo, hi)`` after the kernels of each block
+have been enqueued -- blocks finish in exactly reverse parameter order, so ready ranges are
+contiguous slices.  Slices are merged into buckets of ``bucket_bytes`` and all-reduced with
+``async_op=True``: ProcessGroupNCCL (= RCCL on ROCm) runs the collective on its own side stream
+after waiting for the work already enqueued on the compute stream, so communication of
+decoder/bottleneck gradients overlaps the encoder backward kernels; ``finish()`` makes the compute
+stream wait for the outstanding collectives before autograd hands the gradients to the optimizer.
+Large buckets (default 32 MiB) keep each xGMI link busy with few, large messages.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class DataParallel:
+    def __init__(self, model, process_group=None, bucket_bytes=32 << 20, broadcast=True):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed must be initialised (backend 'nccl' = RCCL on ROCm, or 'gloo')")
+        self.model = model
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group)
+        self.bucket_elems = max(1, bucket_bytes // 4)
+        self.backend = dist.get_backend(process_group)
+        self._works = []
+        self._pending = None            # (flat, lo, hi) not yet launched
+        self._flat = None
+        self.stats = {"buckets": 0, "elems": 0}
+        if broadcast:
+            self.broadcast_state()
+        model.grad_ready_hook = self._on_ready
+        model.grad_sync_finish = self.finish
+
+    # -------------------------------------------------------------- replication
+    def broadcast_state(self):
+        """Rank 0's parameters and buffers become everyone's (identical replicas at step 0)."""
+        with torch.no_grad():
+            for t in list(self.model.parameters()) + list(self.model.buffers()):
+                dist.broadcast(t.data, src=0, group=self.pg)
+
+    # -------------------------------------------------------------- gradient exchange
+    def _launch(self, flat, lo, hi):
+        view = flat[lo:hi]
+        if self.backend == "nccl":
+            work = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
+            self._works.append((work, None))
+        else:  # gloo has no AVG
+            work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            self._works.append((work, view))
+        self.stats["buckets"] += 1
+        self.stats["elems"] += hi - lo
+
+    def _on_ready(self, flat, lo, hi):
+        """Called by the backward schedule: gradients flat[lo:hi] are enqueued on the compute stream."""
+        if self.world == 1:
+            return
+        if self._pending is not None and self._pending[0] is flat and self._pending[1] == hi:
+            lo, hi = lo, self._pending[2]                   # extend the pending range downwards
+        elif self._pending is not None:
+            self._launch(*self._pending)
+        self._pending = (flat, lo, hi)
+        if hi - lo >= self.bucket_elems:
+            self._launch(flat, lo, hi)
+            self._pending = None
+
+    def finish(self):
+        """Flush the last bucket and make the compute stream wait for every collective."""
+        if self._pending is not None:
+            self._launch(*self._pending)
+            self._pending = None
+        for work, view in self._works:
+            work.wait()
+            if view is not None:
+                view.div_(self.world)
+        self._works.clear()
+
+    # -------------------------------------------------------------- fallback for the ATen-CPU path
+    def sync_gradients(self):
+        """All-reduce ``param.grad`` of every parameter (used when backward did not go through the
+        HIP engine, i.e. CPU tensors with the gloo backend)."""
+        params = [p for p in self.model.parameters() if p.grad is not None]
+        if self.world == 1 or not params:
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in params])
+        n = flat.numel()
+        hi = n
+        while hi > 0:
+            lo = max(0, hi - self.bucket_elems)
+            self._on_ready(flat, lo, hi)
+            hi = lo
+        self.finish()
+        o = 0
+        for p in params:
+            p.grad.copy_(flat[o:o + p.numel()].view_as(p.grad))
+            o += p.numel()
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from the torchrun environment; returns (rank, local_rank, world)."""
+    import os
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world

@@ -406,6 +406,9 @@ class _UNetFunction(torch.autograd.Function):
     def backward(ctx, dprobs):
         eng = ctx.engine
         flat = eng.backward(dprobs)
+        finish = eng.model.grad_sync_finish
+        if finish is not None:           # data parallel: wait (stream-side) for the bucket all-reduces
+            finish()
         grads = []
         for p, o in zip(eng.params, eng.poffs):
             grads.append(flat[o:o + p.numel()].view_as(p) if p.requires_grad else None)

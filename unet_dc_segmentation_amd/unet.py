@@ -62,6 +62,7 @@ class _UNetFamily(nn.Module):
         self.compute_dtype = "f32"
         self._engine = None
         self.grad_ready_hook = None      # set by the data-parallel wrapper (dp.py)
+        self.grad_sync_finish = None
 
     # ------------------------------------------------------------------ configuration
     def set_compute_dtype(self, name):
