@@ -1,0 +1,61 @@
+"""CPU: the C-ABI shared library loads and exports every symbol include/unetdc_hip.h declares
+(no compute calls -- there is no GPU here), and the ctypes table mirrors the header."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "unetdc_hip.h")
+
+
+def declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(unetdc_[a-z0-9_A-Z]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from unet_dc_segmentation_amd import build
+    build.build(force=False, verbose=False)            # hipcc cross-compiles gfx950 without a GPU
+    from unet_dc_segmentation_amd import _lib
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = declared()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), n
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "unet_dc_segmentation_amd",
+                                                                     "libunetdc_hip.so")],
+                         capture_output=True, text=True).stdout
+    exported = set(re.findall(r"\bT (unetdc_\w+)", out))
+    assert set(names) <= exported, set(names) - exported
+
+
+def test_ctypes_table_matches_header(lib):
+    from unet_dc_segmentation_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared()
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for name, (_, argtypes) in _lib.SIGNATURES.items():
+        m = re.search(r"\b" + name + r"\s*\(([^;]*?)\)\s*;", src, flags=re.S)
+        assert m, name
+        params = [p for p in m.group(1).split(",") if p.strip() and p.strip() != "void"]
+        assert len(params) == len(argtypes), (name, len(params), len(argtypes))
+
+
+def test_host_only_queries_and_error_reporting(lib):
+    assert lib.unetdc_version() == 1
+    # pure host-side planning queries (no device needed)
+    assert lib.unetdc_conv3x3_stats_rows(8 * 512 * 512, 64) == 8192
+    assert lib.unetdc_conv3x3_stats_rows(8 * 32 * 32, 1024) == 64
+    assert lib.unetdc_conv3x3_wgrad_workspace(8, 512, 512, 64, 64, 1) > 0
+    assert lib.unetdc_bn_relu_bwd_workspace(8, 512, 512, 64, 1, 1) > 0
+    # argument validation happens before any HIP call: bad shapes give a negative code + message
+    rc = lib.unetdc_conv3x3_fwd(None, 64, None, None, None, None, None, 64, None, 1, 8, 8, 64, 64, 1, 0, None)
+    assert rc == -1 and b"null" in lib.unetdc_last_error()
+    rc = lib.unetdc_conv3x3_fwd(None, 64, None, None, None, None, None, 64, None, 0, 8, 8, 64, 64, 1, 0, None)
+    assert rc == -1 and b"geometry" in lib.unetdc_last_error()

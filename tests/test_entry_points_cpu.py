@@ -1,0 +1,103 @@
+"""CPU plumbing tests of the kept entry points (BASELINE config 0: quantify_droplets_batch.py
+inference, random-init U-Net-DC, 4 x 512x512 synthetic images on PyTorch CPU) and of the host
+logic either side of the hot path."""
+import math
+import os
+
+import numpy as np
+import pandas as pd
+import torch
+from PIL import Image
+
+
+def _disc_image(rng, size=96, n=6):
+    img = (rng.random((size, size, 3)) * 60).astype(np.uint8)
+    yy, xx = np.mgrid[0:size, 0:size]
+    for _ in range(n):
+        cy, cx, r = rng.integers(8, size - 8), rng.integers(8, size - 8), rng.integers(2, 7)
+        img[(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = 230
+    return img
+
+
+def test_quantify_known_answers():
+    """equivalent_diameter = sqrt(4*area/pi) and area_sqmicron = area/px^2 -- the format known answers
+    of the reference's sample output (outputs/all_droplets.csv:2: area 18224 -> 152.327, px 3.45)."""
+    import quantify_droplets_batch as q
+    mask = np.zeros((40, 40), np.uint8)
+    mask[2:6, 2:6] = 1            # 16 px square
+    mask[10:12, 10] = 1           # 2 px (removed by min_area=3)
+    mask[20, 20] = 1              # diagonal neighbours are separate objects (4-connectivity)
+    mask[21, 21] = 1
+    df = q.quantify(mask, 1, 3.45)
+    assert len(df) == 4 and list(df.columns) == ["label", "area", "equivalent_diameter", "centroid-0", "centroid-1",
+                                                 "area_sqmicron", "eq_diam_micron"]
+    row = df[df["area"] == 16].iloc[0]
+    assert abs(row["equivalent_diameter"] - math.sqrt(4 * 16 / math.pi)) < 1e-9
+    assert abs(row["area_sqmicron"] - 16 / 3.45 ** 2) < 1e-9 and abs(row["centroid-0"] - 3.5) < 1e-9
+    assert len(q.quantify(mask, 3, None)) == 1
+    assert abs(math.sqrt(4 * 18224 / math.pi) - 152.327) < 1e-3
+    assert q.quantify(np.zeros((8, 8), np.uint8), 1, None).empty
+
+
+def test_quantify_cli_cpu(tmp_path, monkeypatch):
+    import quantify_droplets_batch as q
+    from models.model_2 import UNetDC
+    monkeypatch.setattr(q, "DEVICE", "cpu")
+    monkeypatch.setattr(q, "IMG_SIZE", 64)          # keep the CPU run short; 512 is exercised on the GPU box
+    rng = np.random.default_rng(0)
+    img_dir = tmp_path / "imgs"
+    img_dir.mkdir()
+    for i in range(4):
+        Image.fromarray(_disc_image(rng)).save(img_dir / f"im{i}.png")
+    torch.manual_seed(0)
+    ckpt = tmp_path / "best_UNetDC_focal_model.pth"
+    torch.save(UNetDC(3, 1).state_dict(), ckpt)
+    out = q.main(["--img_dir", str(img_dir), "--ckpt_path", str(ckpt), "--out_dir", str(tmp_path / "out"),
+                  "--batch", "3", "--prob_thresh", "0.3", "--skip_excel", "--skip_histogram", "--save_overlays",
+                  "--background_radius", "15", "--px_per_micron", "3.45"])
+    summary = pd.read_csv(out / "summary_per_image.csv")
+    assert list(summary.columns) == ["filename", "droplet_count", "total_area_px"] and len(summary) == 4
+    for i in range(4):
+        m = np.array(Image.open(out / "predicted_masks" / f"im{i}_pred.png"))
+        assert m.shape == (96, 96) and set(np.unique(m)).issubset({0, 255})
+        assert (out / "overlays" / f"im{i}_overlay.png").exists()
+
+
+def test_rolling_ball_and_dataset(tmp_path):
+    from utils.data_loader import SegmentationDataset, SyntheticDropletDataset, rolling_ball_correction_rgb
+    rng = np.random.default_rng(1)
+    img = _disc_image(rng)
+    out = rolling_ball_correction_rgb(img, 15)
+    assert out.shape == img.shape and out.dtype == np.uint8 and out.max() == 255 and out.min() == 0
+    (tmp_path / "i").mkdir()
+    (tmp_path / "m").mkdir()
+    Image.fromarray(img).save(tmp_path / "i" / "a.png")
+    Image.fromarray(((img[..., 0] > 200) * 255).astype(np.uint8)).save(tmp_path / "m" / "a.png")
+    ds = SegmentationDataset(str(tmp_path / "i"), str(tmp_path / "m"), ["a.png"], ["a.png"], size=64, radius=15)
+    x, m, (oh, ow), name = ds[0]
+    assert x.shape == (3, 64, 64) and m.shape == (1, 64, 64) and (oh, ow) == (96, 96) and name == "a.png"
+    assert 0.0 <= float(x.min()) and float(x.max()) <= 1.0 and set(m.unique().tolist()) <= {0.0, 1.0}
+    s = SyntheticDropletDataset(3, 64, 1, seed=3)[1]
+    assert s[0].shape == (1, 64, 64) and s[1].shape == (1, 64, 64) and 0 < float(s[1].mean()) < 0.5
+
+
+def test_train_entry_point_cpu(tmp_path):
+    import train_DC_focal as t
+    ckpt = tmp_path / "best.pth"
+    hist = t.main(["--synthetic", "--synthetic_len", "10", "--img_size", "32", "--batch", "2", "--epochs", "1",
+                   "--steps", "2", "--workers", "0", "--in_channels", "1", "--device", "cpu",
+                   "--ckpt_path", str(ckpt)])
+    assert len(hist) == 1 and np.isfinite(hist[0]["train_loss"]) and np.isfinite(hist[0]["val_loss"])
+    if ckpt.exists():
+        sd = torch.load(ckpt, weights_only=True)
+        assert len(sd) == 136
+
+
+def test_hip_path_fails_loudly_without_library(monkeypatch, tmp_path):
+    """No silent fallback: a missing libunetdc_hip.so is an error, not a PyTorch code path."""
+    import pytest
+    from unet_dc_segmentation_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.UnetdcError, match="not found"):
+        _lib.load()

@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Training entry point -- drop-in for the reference's ``train_DC_focal.py`` on the MI355X path.
+
+The reference is a module-level script with hard-coded constants; this keeps its loop
+(train_DC_focal.py:241-358: Adam lr 1e-3, 15 epochs, batch 8, focal+dice (1.0, 2.0, 0.3),
+0.3 threshold metrics, early stopping on validation Dice with patience 5, best ``state_dict`` saved
+to ``best_UNetDC_focal_model.pth``) behind argparse flags whose defaults are those constants.
+New: ``--synthetic`` (seeded droplet tiles, no dataset needed), ``--dtype`` (f32 | bf16 compute on
+the HIP path), ``--steps`` (cap the steps per epoch), and data-parallel training when launched with
+``python -m torch.distributed.run --nproc-per-node N train_DC_focal.py ...`` (RCCL all-reduce
+overlapped with backward, unet_dc_segmentation_amd/dp.py).  PNG dumps / plots of the reference's
+test section (:365-611) are visualisation and out of scope.
+"""
+import argparse
+import os
+import time
+
+import torch
+from torch.utils.data import DataLoader, Subset
+
+from unet_dc_segmentation_amd import dp as dpmod
+from utils.data_loader import SegmentationDataset, SyntheticDropletDataset, flip_rotate_augment
+from utils.metrics_DC import combined_loss, dice_coef, focal_dice_loss
+
+
+def build_parser(arch="unetdc", epochs=15, ckpt="best_UNetDC_focal_model.pth", loss="focal_dice"):
+    p = argparse.ArgumentParser("Train the U-Net(-DC) segmentation model")
+    p.add_argument("--image_dir")
+    p.add_argument("--mask_dir")
+    p.add_argument("--synthetic", action="store_true", help="seeded synthetic droplet tiles instead of a dataset")
+    p.add_argument("--synthetic_len", type=int, default=64)
+    p.add_argument("--arch", default=arch, choices=["unetdc", "unet"])
+    p.add_argument("--in_channels", type=int, default=3)
+    p.add_argument("--img_size", type=int, default=512)
+    p.add_argument("--batch", type=int, default=8)
+    p.add_argument("--epochs", type=int, default=epochs)
+    p.add_argument("--lr", type=float, default=1e-3)
+    p.add_argument("--patience", type=int, default=5)
+    p.add_argument("--loss", default=loss, choices=["focal_dice", "bce_dice"])
+    p.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    p.add_argument("--steps", type=int, default=0, help="max training steps per epoch (0 = all)")
+    p.add_argument("--workers", type=int, default=4)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--ckpt_path", default=ckpt)
+    p.add_argument("--device", default="cuda" if torch.cuda.is_available() else "cpu")
+    return p
+
+
+def make_datasets(args):
+    if args.synthetic:
+        full = SyntheticDropletDataset(args.synthetic_len, args.img_size, args.in_channels, seed=args.seed)
+        n = len(full)
+        idx = torch.randperm(n, generator=torch.Generator().manual_seed(args.seed)).tolist()
+        n_test, n_val = max(1, n // 5), max(1, n // 5)                    # 60/20/20 like the reference
+        return (Subset(full, idx[n_test + n_val:]), Subset(full, idx[n_test:n_test + n_val]),
+                Subset(full, idx[:n_test]))
+    if not args.image_dir or not args.mask_dir:
+        raise SystemExit("--image_dir and --mask_dir are required unless --synthetic is given")
+    exts = (".png", ".jpg", ".jpeg", ".tif")
+    imgs = sorted(f for f in os.listdir(args.image_dir) if f.lower().endswith(exts))
+    masks = sorted(f for f in os.listdir(args.mask_dir) if f.lower().endswith(exts))
+    assert len(imgs) == len(masks), "Mismatch between the number of images and masks!"
+    idx = torch.randperm(len(imgs), generator=torch.Generator().manual_seed(args.seed)).tolist()
+    n_test = max(1, len(imgs) // 5)
+    n_val = max(1, (len(imgs) - n_test) // 4)
+    pick = lambda ids: ([imgs[i] for i in ids], [masks[i] for i in ids])   # noqa: E731
+    tr, va, te = pick(idx[n_test + n_val:]), pick(idx[n_test:n_test + n_val]), pick(idx[:n_test])
+    mk = lambda pair, tf: SegmentationDataset(args.image_dir, args.mask_dir, pair[0], pair[1], transform=tf,  # noqa: E731
+                                              size=args.img_size)
+    return mk(tr, flip_rotate_augment(args.seed)), mk(va, None), mk(te, None)
+
+
+def main(argv=None, parser=None):
+    args = (parser or build_parser()).parse_args(argv)
+    rank, local, world = dpmod.init_from_env()
+    device = torch.device(args.device if args.device != "cuda" else f"cuda:{local}")
+    if device.type == "cuda":
+        torch.cuda.set_device(device)
+    torch.manual_seed(args.seed)
+    if args.arch == "unetdc":
+        from models.model_2 import UNetDC as Net
+    else:
+        from models.model import UNet as Net
+    model = Net(in_channels=args.in_channels, out_channels=1).to(device)
+    model.set_compute_dtype(args.dtype)
+    wrapper = dpmod.DataParallel(model) if world > 1 else None
+    if args.loss == "focal_dice":
+        criterion = lambda pred, tgt: focal_dice_loss(pred, tgt, alpha=1.0, gamma=2.0, ratio=0.3)  # noqa: E731
+    else:
+        criterion = combined_loss
+    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)
+
+    train_ds, val_ds, _ = make_datasets(args)
+    if world > 1:                                           # each rank draws its own shard
+        train_ds = Subset(train_ds, list(range(rank, len(train_ds), world)))
+    pin = device.type == "cuda"
+    train_loader = DataLoader(train_ds, batch_size=args.batch, shuffle=True, num_workers=args.workers,
+                              pin_memory=pin, drop_last=True)
+    val_loader = DataLoader(val_ds, batch_size=args.batch, shuffle=False, num_workers=args.workers, pin_memory=pin)
+    if rank == 0:
+        print(f"Training set: {len(train_ds)} images/rank, validation set: {len(val_ds)} images, "
+              f"{world} rank(s), device {device}, compute {args.dtype}")
+
+    best_dice, patience_counter = 0.0, 0
+    history = []
+    for epoch in range(args.epochs):
+        model.train()
+        tr_loss = tr_dice = 0.0
+        correct = total = 0
+        t0, seen = time.time(), 0
+        for step, batch in enumerate(train_loader):
+            if args.steps and step >= args.steps:
+                break
+            images, masks = batch[0].float().to(device, non_blocking=True), batch[1].float().to(device, non_blocking=True)
+            optimizer.zero_grad()
+            outputs = model(images)
+            loss = criterion(outputs, masks)
+            loss.backward()
+            if wrapper is not None and not images.is_cuda:
+                wrapper.sync_gradients()                    # ATen-CPU path: explicit all-reduce
+            optimizer.step()
+            tr_loss += loss.item()
+            pred = (outputs > 0.3).float()
+            tr_dice += dice_coef(masks, pred).item()
+            correct += int((pred == masks).sum().item())
+            total += masks.numel()
+            seen += images.shape[0]
+        nb = max(1, min(len(train_loader), args.steps or len(train_loader)))
+        dt = time.time() - t0
+        # -------- validation --------
+        model.eval()
+        va_loss = va_dice = 0.0
+        vc = vt = 0
+        with torch.no_grad():
+            for batch in val_loader:
+                images, masks = batch[0].float().to(device), batch[1].float().to(device)
+                outputs = model(images)
+                va_loss += criterion(outputs, masks).item()
+                pred = (outputs > 0.3).float()
+                va_dice += dice_coef(masks, pred).item()
+                vc += int((pred == masks).sum().item())
+                vt += masks.numel()
+        nv = max(1, len(val_loader))
+        rec = dict(epoch=epoch + 1, train_loss=tr_loss / nb, val_loss=va_loss / nv, train_dice=tr_dice / nb,
+                   val_dice=va_dice / nv, train_acc=correct / max(total, 1), val_acc=vc / max(vt, 1),
+                   images_per_sec=seen * world / max(dt, 1e-9))
+        history.append(rec)
+        if rank == 0:
+            print(f"Epoch {epoch + 1}/{args.epochs} | Train Loss: {rec['train_loss']:.4f}, Val Loss: {rec['val_loss']:.4f}, "
+                  f"Train Dice: {rec['train_dice']:.4f}, Val Dice: {rec['val_dice']:.4f}")
+            print(f"Train Acc: {rec['train_acc']:.4f}, Val Acc: {rec['val_acc']:.4f} | {rec['images_per_sec']:.1f} img/s")
+            print("-------------------------------------------------------")
+        if rec["val_dice"] > best_dice:
+            best_dice, patience_counter = rec["val_dice"], 0
+            if rank == 0:
+                torch.save(model.state_dict(), args.ckpt_path)
+                print("Model saved!")
+        else:
+            patience_counter += 1
+        if patience_counter >= args.patience:
+            if rank == 0:
+                print("Early stopping!")
+            break
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    return history
+
+
+if __name__ == "__main__":
+    main()
