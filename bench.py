@@ -81,6 +81,40 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("UNETDC_BENCH_CPU_CORES", "16"))))
 
 
+def per_layer_table(step, args):
+    """Diagnostic: time every C-ABI call of one step with HIP events and print name/shape/ms/TFLOP/s."""
+    from unet_dc_segmentation_amd import _lib
+    names = [n for n in _lib.SIGNATURES if n not in ("unetdc_version", "unetdc_last_error") and "workspace" not in n
+             and "rows" not in n]
+    _lib.start_timing(names)
+    for _ in range(3):
+        step()
+    rec = _lib.stop_timing()
+    per = len(rec) // 3
+    rows = rec[2 * per:]
+    tot = {}
+    for name, a, ms in rows:
+        fl, shape = 0.0, ""
+        ints = [v for v in a if isinstance(v, int) and 0 < v < 100000]
+        if name in ("unetdc_conv3x3_fwd", "unetdc_conv3x3_dgrad", "unetdc_convT2x2_fwd", "unetdc_convT2x2_dgrad"):
+            fl, _ = igemm_flops(name, a)
+        elif name == "unetdc_conv3x3_wgrad":
+            n, h, w, cin, cout = a[7:12]
+            fl = 2.0 * n * h * w * cin * cout * 9
+        elif name == "unetdc_convT2x2_wgrad":
+            n, h, w, cin, cout = a[7:12]
+            fl = 2.0 * n * h * w * cin * cout * 4
+        shape = "x".join(str(v) for v in ints[-8:])
+        print(f"{name:32s} {shape:40s} {ms * 1e3:9.1f} us {fl / (ms * 1e-3) / 1e12 if fl else 0:8.1f} TF", file=sys.stderr)
+        t = tot.setdefault(name, [0.0, 0.0])
+        t[0] += ms
+        t[1] += fl
+    print("---- per entry point (one step) ----", file=sys.stderr)
+    for name, (ms, fl) in sorted(tot.items(), key=lambda kv: -kv[1][0]):
+        print(f"{name:32s} {ms:8.3f} ms {fl / (ms * 1e-3) / 1e12 if fl else 0:8.1f} TF", file=sys.stderr)
+    print(f"sum {sum(v[0] for v in tot.values()):.3f} ms", file=sys.stderr)
+
+
 def cpu_baseline(batch, h, w, cin):
     """CPU port of the reference path: forward + focal/dice loss + backward on the host cores."""
     from oracle import unetdc_torch_cpu as otc
@@ -113,6 +147,7 @@ def main():
     ap.add_argument("--arch", default="unetdc", choices=["unetdc", "unet"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--per-layer", action="store_true", help="print a per-call timing table to stderr (diagnostic)")
     args = ap.parse_args()
 
     from unet_dc_segmentation_amd import _lib, dp as dpmod
@@ -148,6 +183,8 @@ def main():
     for _ in range(args.warmup):
         step()
     igemm_calls = ["unetdc_conv3x3_fwd", "unetdc_conv3x3_dgrad", "unetdc_convT2x2_fwd", "unetdc_convT2x2_dgrad"]
+    if args.per_layer:
+        per_layer_table(step, args)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

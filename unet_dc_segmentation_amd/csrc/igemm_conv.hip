@@ -26,6 +26,8 @@
 //     of step s; one barrier per K-step.
 //   * taps whose shifted window misses the image for the whole block are skipped (bottleneck
 //     d=16 on a 32x32 map: 5 of 9 taps for most blocks).
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace unetdc {
@@ -268,12 +270,22 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(const IgemmParams p)
 }
 
 // ------------------------------------------------------------------------------------------------
-static bool use_wide_tile(long M, int Cout) {
-  // 128x128 tiles when the channel count allows it, otherwise 256 pixels x 64 channels
-  return (Cout % 128 == 0);
-}
+// defined in igemm_dma.hip (second-generation kernel, used whenever the tensors are < 2 GiB)
+bool igemm_dma_supported(const IgemmParams& p, int dtype);
+int launch_igemm_dma(IgemmParams& p, int dtype, hipStream_t stream);
 
-int igemm_mblocks(long M, int Cout) { return ceil_div(M, use_wide_tile(M, Cout) ? 128 : 256); }
+// Every configuration that can be asked for BatchNorm statistics uses 256-pixel M blocks, so the
+// number of partial-statistics rows is a function of the pixel count only.
+int igemm_mblocks(long M, int Cout) { (void)Cout; return ceil_div(M, 256); }
+
+static bool use_legacy() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("UNETDC_IGEMM");
+    v = (e && e[0] == 'l') ? 1 : 0;        // UNETDC_IGEMM=legacy: first-generation register-staged kernel
+  }
+  return v == 1;
+}
 
 template <typename T, int WM, int WN>
 static int launch_cfg(IgemmParams& p, hipStream_t stream) {
@@ -312,7 +324,8 @@ int launch_igemm(IgemmParams& p, int dtype, hipStream_t stream) {
   if (p.mode == MODE_SHUFFLE) UNETDC_REQUIRE(p.shuf_c % 64 == 0, "igemm: convT channels must be a multiple of 64");
   if (p.mode == MODE_STATS) UNETDC_REQUIRE(p.stats != nullptr, "igemm: stats buffer missing");
   if (p.mode == MODE_AFFINE_RELU) UNETDC_REQUIRE(p.scale && p.shift, "igemm: scale/shift missing");
-  const bool wide = use_wide_tile(p.M, p.Cout);
+  if (!use_legacy() && igemm_dma_supported(p, dtype)) return launch_igemm_dma(p, dtype, stream);
+  const bool wide = (p.Cout % 128 == 0) && p.mode != MODE_STATS;     // statistics rows assume BM = 256
   if (dtype == UNETDC_BF16)
     return wide ? launch_cfg<bf16_t, 2, 2>(p, stream) : launch_cfg<bf16_t, 4, 1>(p, stream);
   return wide ? launch_cfg<float, 2, 2>(p, stream) : launch_cfg<float, 4, 1>(p, stream);

@@ -1,0 +1,319 @@
+// Second-generation implicit-GEMM convolution: same math and epilogues as igemm_conv.hip, but the
+// A (shifted pixels) and B (weights) tiles travel HBM/L2 -> LDS by LDS-DMA
+// (`buffer_load_dwordx4 ... offen lds`), never through VGPRs:
+//   * no ds_write pass (register->LDS stores top out at ~79 B/clk/CU on gfx950 and made the
+//     first-generation 128x128 tile LDS-pipe-bound at 23 % of the MFMA peak),
+//   * zero padding for free: a lane whose shifted pixel falls outside the image gets a byte offset
+//     beyond the buffer descriptor's range, and the hardware writes zeros into LDS for it
+//     (verified on MI355X: tools/probes/dma_oob.hip),
+//   * the LDS image of a DMA is lane-linear (base + lane*16 B): 8 lanes cover one 128-byte row, one
+//     wave-instruction covers 8 rows; the bank-conflict XOR swizzle is therefore applied on the
+//     SOURCE side (lane with physical chunk pc of row R fetches logical chunk pc ^ ((R>>1)&7)),
+//     and the same XOR on the ds_read_b128 fragment reads,
+//   * 256-pixel block tiles (8 waves for the wide configurations) halve the bytes per FLOP that
+//     have to cross L2 -> LDS compared with 128x128.
+// Pipeline: two LDS stages, ONE barrier per K-step:  wait(my DMAs of step s) ; barrier ;
+// issue DMAs of step s+1 into the other stage ; ds_read + MFMA on stage s.
+#include "kernels.h"
+
+namespace unetdc {
+
+template <typename T> struct MmaD;
+template <> struct MmaD<bf16_t> {
+  __device__ static __forceinline__ void run(f32x16& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                  acc, 0, 0, 0);
+  }
+};
+template <> struct MmaD<float> {
+  __device__ static __forceinline__ void run(f32x16& acc, const u32x4& a, const u32x4& b) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const unsigned int ua = a[s], ub = b[s];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bits_f32(ua), bits_f32(ub), acc, 0, 0, 0);
+    }
+  }
+};
+
+template <typename T> __device__ __forceinline__ void store_pair_d(T* dst, float v0, float v1);
+template <> __device__ __forceinline__ void store_pair_d<float>(float* dst, float v0, float v1) {
+  *reinterpret_cast<float2*>(dst) = make_float2(v0, v1);
+}
+template <> __device__ __forceinline__ void store_pair_d<bf16_t>(bf16_t* dst, float v0, float v1) {
+  bf16_t lo = (bf16_t)v0, hi = (bf16_t)v1;
+  *reinterpret_cast<unsigned int*>(dst) = (unsigned int)__builtin_bit_cast(unsigned short, lo) |
+                                          ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
+}
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+constexpr unsigned OOB = 0x80000000u;       // byte offset beyond any descriptor range (< 2 GiB tensors)
+
+// WM x WN waves; each wave owns (TM*32) x 64 outputs (TM x 2 MFMA 32x32 tiles).
+template <typename T, int WM, int WN, int TM>
+__global__ __launch_bounds__(512, 2) void igemm_dma_kernel(const IgemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins exist only in the device pass
+  constexpr int NW = WM * WN;                   // waves per block
+  constexpr int BM = WM * TM * 32, BN = WN * 64;
+  constexpr int AI = BM / 8 / NW, BI = BN / 8 / NW;   // DMA wave-instructions per wave per K-step
+  constexpr int ES = (int)sizeof(T);
+  constexpr int KE = 128 / ES;                  // channels per K-step
+  constexpr int STAGE = (BM + BN) * 128;
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/wave mismatch");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int mblk = tile / p.nblocks, nblk = tile - mblk * p.nblocks;
+  const int m0 = mblk * BM, n0 = nblk * BN;
+  const int HoWo = p.Ho * p.Wo;
+
+  // buffer descriptors (wave-uniform: built from kernel arguments only)
+  const unsigned xbytes = (unsigned)(((long)p.M / HoWo) * p.Hi * p.Wi * p.ldx * ES);      // upper bound on the view
+  const unsigned wbytes = (unsigned)((long)p.ntaps * p.Cout * p.Cin * ES);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, wbytes, 0x00020000);
+
+  // ---- per-lane description of the A rows this lane feeds (row = 8*instr + lane/8) -------------
+  const int sub = lane >> 3, pc = lane & 7;
+  int ys[AI], xs[AI];
+  unsigned abase[AI];                            // byte offset of (pixel, swizzled chunk) at tap 0,0 / kc 0
+  unsigned tapmask = 0;
+#pragma unroll
+  for (int j = 0; j < AI; ++j) {
+    const int row = (wave + NW * j) * 8 + sub;
+    const int m = m0 + row;
+    const int c = pc ^ ((row >> 1) & 7);
+    if (m < p.M) {
+      const int n = m / HoWo, rem = m - n * HoWo;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      ys[j] = oy * p.stride;
+      xs[j] = ox * p.stride;
+      abase[j] = (unsigned)(((n * p.Hi + ys[j]) * p.Wi + xs[j]) * p.ldx * ES + c * 16);
+    } else {
+      ys[j] = -(1 << 28);
+      xs[j] = 0;
+      abase[j] = 0;
+    }
+    for (int t = 0; t < p.ntaps; ++t) {
+      const int iy = ys[j] + p.offy[t], ix = xs[j] + p.offx[t];
+      if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) tapmask |= 1u << t;
+    }
+  }
+  // B rows: LDS row lrow holds output channel grp*64 + 2*(q&31) + (q>>5) (even channels first)
+  unsigned bbase[BI];
+#pragma unroll
+  for (int j = 0; j < BI; ++j) {
+    const int lrow = (wave + NW * j) * 8 + sub;
+    const int grp = lrow >> 6, q = lrow & 63;
+    const int cc = (q & 31) * 2 + (q >> 5);
+    const int c = pc ^ ((lrow >> 1) & 7);
+    bbase[j] = (unsigned)((n0 + grp * 64 + cc) * p.Cin * ES + c * 16);
+  }
+  {
+    unsigned* sm_u = reinterpret_cast<unsigned*>(smem);
+    if (tid == 0) sm_u[0] = 0;
+    __syncthreads();
+    if (tapmask) atomicOr(&sm_u[0], tapmask);
+    __syncthreads();
+    tapmask = sm_u[0];
+    __syncthreads();
+  }
+  const int nkc = p.Cin / KE;
+  const int nsteps = __popc(tapmask) * nkc;
+
+  // ---- fragment read offsets --------------------------------------------------------------------
+  const int r = lane & 31, h = lane >> 5;
+  const int swz_r = (r >> 1) & 7;
+  int a_rd[4], b_rd[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int ch = ((2 * g + h) ^ swz_r) << 4;
+    a_rd[g] = (wm * TM * 32 + r) * 128 + ch;
+    b_rd[g] = BM * 128 + (wn * 64 + r) * 128 + ch;
+  }
+
+  f32x16 acc[TM][2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  int lt = 0, lkc = 0;
+  while (lt < p.ntaps && !((tapmask >> lt) & 1u)) ++lt;
+
+  auto issue = [&](int stage) {
+    const int dy = p.offy[lt], dx = p.offx[lt];
+    const unsigned dbytes = (unsigned)((dy * p.Wi + dx) * p.ldx * ES + lkc * 128);
+    unsigned char* sbase = smem + stage * STAGE;
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {
+      const int iy = ys[j] + dy, ix = xs[j] + dx;
+      const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      const unsigned voff = ok ? abase[j] + dbytes : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, LDS_PTR(sbase + (wave + NW * j) * 1024), 16, voff, 0, 0, 0);
+    }
+    const unsigned wbytes_t = (unsigned)(lt * p.Cout * p.Cin * ES + lkc * 128);
+#pragma unroll
+    for (int j = 0; j < BI; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, LDS_PTR(sbase + BM * 128 + (wave + NW * j) * 1024), 16,
+                                               bbase[j] + wbytes_t, 0, 0, 0);
+    if (++lkc == nkc) {
+      lkc = 0;
+      do { ++lt; } while (lt < p.ntaps && !((tapmask >> lt) & 1u));
+    }
+  };
+
+  if (nsteps > 0) issue(0);
+  for (int s = 0; s < nsteps; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my DMAs of step s have landed
+    __syncthreads();                                       // ... everyone's; and stage (s+1)&1 is free
+    if (s + 1 < nsteps) issue((s + 1) & 1);
+    const unsigned char* base = smem + (s & 1) * STAGE;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      u32x4 a[TM], b[2];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = ld16(base + a_rd[g] + i * 32 * 128);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = ld16(base + b_rd[g] + j * 32 * 128);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) MmaD<T>::run(acc[i][j], a[i], b[j]);
+    }
+  }
+
+  // ---- epilogue: straight from the accumulators -----------------------------------------------
+  const int col = n0 + wn * 64 + 2 * r;
+  T* __restrict__ og = reinterpret_cast<T*>(p.out);
+  float k0a = 0.f, k0b = 0.f, k1a = 0.f, k1b = 0.f;
+  int shuf_ab = 0, shuf_co = col;
+  if (p.mode == MODE_AFFINE_RELU) {
+    k0a = p.scale[col]; k0b = p.scale[col + 1];
+    k1a = p.shift[col]; k1b = p.shift[col + 1];
+  } else if (p.mode == MODE_SHUFFLE) {
+    shuf_ab = col / p.shuf_c;
+    shuf_co = col - shuf_ab * p.shuf_c;
+    if (p.bias) { k1a = p.bias[shuf_co]; k1b = p.bias[shuf_co + 1]; }
+  } else if (p.bias) {
+    k1a = p.bias[col]; k1b = p.bias[col + 1];
+  }
+  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+  const bool fastrow = (p.Wo & 31) == 0;        // a 32-row MFMA tile then lies inside one image row
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi) {
+    const int mb = m0 + (wm * TM + mi) * 32;
+    int bn = 0, boy = 0, box = 0;
+    if (p.mode == MODE_SHUFFLE && fastrow) {
+      bn = mb / HoWo;
+      const int rem = mb - bn * HoWo;
+      boy = rem / p.Wo;
+      box = rem - boy * p.Wo;
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int roff = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      const int m = mb + roff;
+      if (m >= p.M) continue;
+      float v0 = acc[mi][0][reg], v1 = acc[mi][1][reg];
+      if (p.mode == MODE_AFFINE_RELU) {
+        v0 = fmaxf(fmaf(v0, k0a, k1a), 0.f);
+        v1 = fmaxf(fmaf(v1, k0b, k1b), 0.f);
+        store_pair_d<T>(og + (long)m * p.ldo + col, v0, v1);
+      } else if (p.mode == MODE_SHUFFLE) {
+        v0 += k1a; v1 += k1b;
+        int n = bn, oy = boy, ox = box + roff;
+        if (!fastrow) {
+          n = m / HoWo;
+          const int rem = m - n * HoWo;
+          oy = rem / p.Wo;
+          ox = rem - oy * p.Wo;
+        }
+        const long dst = ((long)(n * 2 * p.Ho + 2 * oy + (shuf_ab >> 1)) * (2 * p.Wo) + 2 * ox + (shuf_ab & 1));
+        store_pair_d<T>(og + dst * p.ldo + shuf_co, v0, v1);
+      } else {
+        v0 += k1a; v1 += k1b;
+        store_pair_d<T>(og + (long)m * p.ldo + col, v0, v1);
+        if (p.mode == MODE_STATS) {
+          const float t0 = round_through<T>(v0), t1 = round_through<T>(v1);
+          s0 += t0; q0 = fmaf(t0, t0, q0);
+          s1 += t1; q1 = fmaf(t1, t1, q1);
+        }
+      }
+    }
+  }
+  if (p.mode == MODE_STATS) {
+    s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
+    s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
+    __syncthreads();                                         // all waves are done with the stage buffers
+    float* red = reinterpret_cast<float*>(smem);             // [wave][4][32]
+    if (h == 0) {
+      red[(wave * 4 + 0) * 32 + r] = s0;
+      red[(wave * 4 + 1) * 32 + r] = q0;
+      red[(wave * 4 + 2) * 32 + r] = s1;
+      red[(wave * 4 + 3) * 32 + r] = q1;
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int wn2 = tid >> 6, c2 = tid & 63, r2 = c2 >> 1, e = c2 & 1;
+      float su = 0.f, sq = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < WM; ++w2) {
+        su += red[((w2 * WN + wn2) * 4 + e * 2 + 0) * 32 + r2];
+        sq += red[((w2 * WN + wn2) * 4 + e * 2 + 1) * 32 + r2];
+      }
+      p.stats[((long)mblk * 2 + 0) * p.Cout + n0 + tid] = su;
+      p.stats[((long)mblk * 2 + 1) * p.Cout + n0 + tid] = sq;
+    }
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T, int WM, int WN, int TM>
+static int launch_dma_cfg(IgemmParams& p, hipStream_t stream) {
+  constexpr int BM = WM * TM * 32, BN = WN * 64;
+  constexpr int LDS = 2 * (BM + BN) * 128;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<T, WM, WN, TM>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(igemm_dma_kernel) failed: %s", hipGetErrorString(e));
+      return UNETDC_ELAUNCH;
+    }
+    attr_done = true;
+  }
+  p.mblocks = ceil_div(p.M, BM);
+  p.nblocks = p.Cout / BN;
+  const long nwg = (long)p.mblocks * p.nblocks;
+  hipLaunchKernelGGL((igemm_dma_kernel<T, WM, WN, TM>), dim3((unsigned)nwg), dim3(WM * WN * 64), LDS, stream, p);
+  return check_launch("igemm_dma_kernel");
+}
+
+// rows of BatchNorm partial statistics the chosen configuration produces (all use BM = 256)
+int igemm_dma_mblocks(long M) { return ceil_div(M, 256); }
+
+bool igemm_dma_supported(const IgemmParams& p, int dtype) {
+  const long es = dtype == UNETDC_BF16 ? 2 : 4;
+  const long HoWo = (long)p.Ho * p.Wo;
+  const long xbytes = (p.M / HoWo) * p.Hi * p.Wi * p.ldx * es;
+  const long wbytes = (long)p.ntaps * p.Cout * p.Cin * es;
+  return xbytes < (1L << 31) && wbytes < (1L << 31) && p.M % HoWo == 0;
+}
+
+int launch_igemm_dma(IgemmParams& p, int dtype, hipStream_t stream) {
+  if (p.Cout % 256 == 0 && p.M >= 256 * 64) {
+    return dtype == UNETDC_BF16 ? launch_dma_cfg<bf16_t, 2, 4, 4>(p, stream) : launch_dma_cfg<float, 2, 4, 4>(p, stream);
+  }
+  if (p.Cout % 128 == 0) {
+    return dtype == UNETDC_BF16 ? launch_dma_cfg<bf16_t, 4, 2, 2>(p, stream) : launch_dma_cfg<float, 4, 2, 2>(p, stream);
+  }
+  return dtype == UNETDC_BF16 ? launch_dma_cfg<bf16_t, 4, 1, 2>(p, stream) : launch_dma_cfg<float, 4, 1, 2>(p, stream);
+}
+
+}  // namespace unetdc

@@ -20,81 +20,12 @@
 // use a 128x128 block tile (2x2 waves).  Across blocks the pixel range is split `ksplit` ways
 // into fp32 partial slabs that a second, deterministic kernel sums and permutes into PyTorch's
 // parameter layout -- no atomics, bitwise reproducible.
+#include <stdlib.h>
+
 #include "kernels.h"
+#include "wgrad_frag.h"
 
 namespace unetdc {
-
-template <typename T, int TW> struct Frag;   // TW = tile width in units of 64 channels
-
-// ---- bf16: transposed LDS reads -----------------------------------------------------------------
-template <int TW> struct Frag<bf16_t, TW> {
-  static constexpr int RB = TW * 128;                     // bytes per pixel row in LDS
-  // byte offset (within an operand's stage image) of 16-byte chunk `ch` of pixel row `row`
-  __device__ static __forceinline__ int wr_off(int row, int ch) {
-    const int byte = ch * 16, unit = byte >> 6, within = byte & 63;
-    const int f = (TW == 1) ? ((row >> 1) & 1) : (row & 3);
-    return row * RB + ((unit ^ f) << 6) + within;
-  }
-  // per-lane base offset for the fragment of 32 channels starting at channel `cbase`,
-  // pixel rows kbase + 16*ks + [0,16): two tr reads (jj = 0,1) at +jj*4 rows.
-  __device__ static __forceinline__ int rd_off(int lane, int cbase, int krow0, int jj) {
-    const int i = lane & 15, G = (lane >> 4) & 3;
-    const int q = i >> 2, pp = i & 3, hi = G & 1, h = G >> 1;
-    const int krow = krow0 + 8 * h + 4 * jj + q;
-    const int byte = (cbase + 16 * hi + 4 * pp) * 2, unit = byte >> 6, within = byte & 63;
-    const int f = (TW == 1) ? ((krow >> 1) & 1) : (krow & 3);
-    return krow * RB + ((unit ^ f) << 6) + within;
-  }
-  // consume 16 pixels (one MFMA K-step)
-  __device__ static __forceinline__ void mma16(f32x16 (&acc)[2][2], const unsigned char* sa, const unsigned char* sb,
-                                               int lane, int ca, int cb, int krow0) {
-    bf16x8 fa[2], fb[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      s16x4 lo, hi;
-      lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (__attribute__((address_space(3))) s16x4*)(sa + rd_off(lane, ca + 32 * t, krow0, 0)));
-      hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (__attribute__((address_space(3))) s16x4*)(sa + rd_off(lane, ca + 32 * t, krow0, 1)));
-      fa[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-      lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (__attribute__((address_space(3))) s16x4*)(sb + rd_off(lane, cb + 32 * t, krow0, 0)));
-      hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (__attribute__((address_space(3))) s16x4*)(sb + rd_off(lane, cb + 32 * t, krow0, 1)));
-      fb[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-  }
-};
-
-// ---- fp32: scalar fragment reads ------------------------------------------------------------------
-template <int TW> struct Frag<float, TW> {
-  static constexpr int RB = TW * 256;
-  __device__ static __forceinline__ int wr_off(int row, int ch) { return row * RB + ch * 16; }
-  __device__ static __forceinline__ void mma16(f32x16 (&acc)[2][2], const unsigned char* sa, const unsigned char* sb,
-                                               int lane, int ca, int cb, int krow0) {
-    const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int kp = 0; kp < 8; ++kp) {
-      const int krow = krow0 + 2 * kp + h;
-      float fa[2], fb[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        fa[t] = *reinterpret_cast<const float*>(sa + krow * RB + (ca + 32 * t + r) * 4);
-        fb[t] = *reinterpret_cast<const float*>(sb + krow * RB + (cb + 32 * t + r) * 4);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
-  }
-};
 
 // TW = 1: 64x64 block tile, the 4 waves split each pixel chunk; TW = 2: 128x128, waves 2x2.
 template <typename T, int TW>
@@ -265,6 +196,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// second-generation (LDS-DMA) kernel, wgrad_dma.hip
+int wgrad_dma_tile(int CI, int CJ);
+int wgrad_dma_pixel_step(int dtype, int tw);
+bool wgrad_dma_supported(const WgradParams& p, int dtype);
+int launch_wgrad_dma_kernel(WgradParams& p, int tw, int dtype, hipStream_t stream);
+
+static bool wgrad_legacy() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("UNETDC_WGRAD");
+    v = (e && e[0] == 'l') ? 1 : 0;        // UNETDC_WGRAD=legacy: first-generation register-staged kernel
+  }
+  return v == 1;
+}
+
 static int pixel_step(int dtype, bool wide) {
   const int rb = (wide ? 2 : 1) * 64 * (dtype == UNETDC_BF16 ? 2 : 4);
   return 16384 / rb;
@@ -272,24 +218,46 @@ static int pixel_step(int dtype, bool wide) {
 
 static bool wgrad_wide(int CI, int CJ) { return CI % 128 == 0 && CJ % 128 == 0; }
 
-static void plan(long P, int CI, int CJ, int ntaps, int dtype, int& ksplit, int& chunk) {
-  const bool wide = wgrad_wide(CI, CJ);
-  const int step = pixel_step(dtype, wide);
-  const int tiles = ntaps * (CI / (wide ? 128 : 64)) * (CJ / (wide ? 128 : 64));
-  long want = (1024 + tiles - 1) / tiles;               // aim at ~4 workgroups per CU
-  const long maxsplit = (P + step - 1) / step;
-  if (want > maxsplit) want = maxsplit;
-  if (want < 1) want = 1;
-  long ch = (P + want - 1) / want;
+// Choose the K split.  The grid is tiles*ksplit workgroups on 256 CUs with `bpc` resident blocks per
+// CU.  Cost model (microseconds): MFMA time at ~1 PFLOP/s divided by the fill efficiency of the
+// last wave of workgroups, plus writing and re-reading ksplit fp32 slabs at ~4 TB/s.
+static void plan(long P, int tiles, int step, int bpc, double slab_bytes, double flops, int& ksplit, int& chunk) {
+  const long maxsplit = (P + (long)step * 4 - 1) / ((long)step * 4);
+  const long slots = 256L * bpc;
+  const double t_mfma = flops / 1.0e15 * 1e6;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int ks = 1; ks <= 160 && ks <= maxsplit; ++ks) {
+    const long blocks = (long)tiles * ks;
+    const long rounds = (blocks + slots - 1) / slots;
+    const double eff = (double)blocks / (double)(rounds * slots);
+    const double cost = t_mfma / eff + 2.0 * ks * slab_bytes / 4.0e12 * 1e6 + 0.02 * ks;
+    if (cost < best_cost) { best_cost = cost; best = ks; }
+  }
+  long ch = (P + best - 1) / best;
   ch = ((ch + step - 1) / step) * step;
   chunk = (int)ch;
   ksplit = (int)((P + ch - 1) / ch);
 }
 
+static void plan_legacy(long P, int CI, int CJ, int ntaps, int dtype, int& ksplit, int& chunk) {
+  const bool wide = wgrad_wide(CI, CJ);
+  const int tiles = ntaps * (CI / (wide ? 128 : 64)) * (CJ / (wide ? 128 : 64));
+  plan(P, tiles, pixel_step(dtype, wide), 2, (double)ntaps * CI * CJ * 4, 2.0 * P * CI * CJ * ntaps, ksplit, chunk);
+}
+
+static void plan_dma(long P, int CI, int CJ, int ntaps, int dtype, int& ksplit, int& chunk) {
+  const int tw = wgrad_dma_tile(CI, CJ);
+  const int tiles = ntaps * (CI / (tw * 64)) * (CJ / (tw * 64));
+  plan(P, tiles, wgrad_dma_pixel_step(dtype, tw), tw == 4 ? 1 : 2, (double)ntaps * CI * CJ * 4,
+       2.0 * P * CI * CJ * ntaps, ksplit, chunk);
+}
+
 long wgrad_workspace_bytes(long P, int CI, int CJ, int ntaps, int dtype) {
-  int ksplit, chunk;
-  plan(P, CI, CJ, ntaps, dtype, ksplit, chunk);
-  return (long)ksplit * ntaps * CI * CJ * 4;
+  int k1, c1, k2, c2;
+  plan_legacy(P, CI, CJ, ntaps, dtype, k1, c1);
+  plan_dma(P, CI, CJ, ntaps, dtype, k2, c2);
+  return (long)(k1 > k2 ? k1 : k2) * ntaps * CI * CJ * 4;
 }
 
 template <typename T, int TW>
@@ -320,21 +288,26 @@ int launch_wgrad(WgradParams& p, float* out, void* workspace, long workspace_byt
   const long P = (long)p.N * p.H * p.W;
   UNETDC_REQUIRE(P > 0 && P < (1L << 31) - 4096, "wgrad: pixel count out of range");
   p.P = (int)P;
+  const bool dma = !wgrad_legacy() && wgrad_dma_supported(p, dtype);
   const bool wide = wgrad_wide(p.CI, p.CJ);
-  plan(P, p.CI, p.CJ, p.ntaps, dtype, p.ksplit, p.chunk);
+  const int tw = dma ? wgrad_dma_tile(p.CI, p.CJ) : (wide ? 2 : 1);
+  if (dma) plan_dma(P, p.CI, p.CJ, p.ntaps, dtype, p.ksplit, p.chunk);
+  else plan_legacy(P, p.CI, p.CJ, p.ntaps, dtype, p.ksplit, p.chunk);
   const long need = (long)p.ksplit * p.ntaps * p.CI * p.CJ * 4;
   if (need > workspace_bytes) {
     set_error("wgrad: workspace too small (%ld < %ld bytes)", workspace_bytes, need);
     return UNETDC_EWORKSPACE;
   }
   p.part = reinterpret_cast<float*>(workspace);
-  p.itiles = p.CI / (wide ? 128 : 64);
-  p.jtiles = p.CJ / (wide ? 128 : 64);
-  const int step = pixel_step(dtype, wide);
+  p.itiles = p.CI / (tw * 64);
+  p.jtiles = p.CJ / (tw * 64);
+  const int step = dma ? wgrad_dma_pixel_step(dtype, tw) : pixel_step(dtype, wide);
   p.adv_y = step / p.W;
   p.adv_x = step % p.W;
   int rc;
-  if (dtype == UNETDC_BF16)
+  if (dma)
+    rc = launch_wgrad_dma_kernel(p, tw, dtype, stream);
+  else if (dtype == UNETDC_BF16)
     rc = wide ? launch_w<bf16_t, 2>(p, stream) : launch_w<bf16_t, 1>(p, stream);
   else
     rc = wide ? launch_w<float, 2>(p, stream) : launch_w<float, 1>(p, stream);
