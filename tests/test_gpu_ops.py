@@ -37,6 +37,11 @@ CONV_CASES = [  # n, h, w, cin, cout, d
     (2, 32, 32, 64, 128, 16),    # d = 16 on a 32x32 map: tap skipping
     (1, 16, 16, 256, 64, 8),     # deep K, narrow N
     (1, 8, 8, 128, 256, 1),      # tiny map
+    # >= 128K pixels, Cout 64/128, d <= 2: routed to the halo-patch kernel (igemm_halo.hip)
+    (2, 256, 256, 64, 64, 1),    # 4-wave config, one K chunk, image borders on all sides
+    (1, 264, 512, 128, 64, 1),   # two K chunks through a single patch buffer; H not a power of two
+    (2, 256, 256, 64, 128, 2),   # 8-wave config, d = 2
+    (1, 512, 256, 128, 128, 2),  # 8-wave config, two K chunks, double-buffered patch
 ]
 
 

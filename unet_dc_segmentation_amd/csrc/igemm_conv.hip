@@ -273,19 +273,25 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(const IgemmParams p)
 // defined in igemm_dma.hip (second-generation kernel, used whenever the tensors are < 2 GiB)
 bool igemm_dma_supported(const IgemmParams& p, int dtype);
 int launch_igemm_dma(IgemmParams& p, int dtype, hipStream_t stream);
+// defined in igemm_halo.hip (LDS-staged input patch shared by all 9 taps; narrow layers, d <= 2)
+bool igemm_halo_supported(const IgemmParams& p, int dtype);
+int launch_igemm_halo(IgemmParams& p, int dtype, hipStream_t stream);
 
 // Every configuration that can be asked for BatchNorm statistics uses 256-pixel M blocks, so the
 // number of partial-statistics rows is a function of the pixel count only.
 int igemm_mblocks(long M, int Cout) { (void)Cout; return ceil_div(M, 256); }
 
-static bool use_legacy() {
+// UNETDC_IGEMM=legacy: first-generation register-staged kernel; =dma: per-tap LDS-DMA kernel only
+// (no halo-patch kernel).  Default: best kernel per layer.  For A/B measurements in one binary.
+static int igemm_choice() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("UNETDC_IGEMM");
-    v = (e && e[0] == 'l') ? 1 : 0;        // UNETDC_IGEMM=legacy: first-generation register-staged kernel
+    v = (e && e[0] == 'l') ? 1 : ((e && e[0] == 'd') ? 2 : 0);
   }
-  return v == 1;
+  return v;
 }
+static bool use_legacy() { return igemm_choice() == 1; }
 
 template <typename T, int WM, int WN>
 static int launch_cfg(IgemmParams& p, hipStream_t stream) {
@@ -324,6 +330,7 @@ int launch_igemm(IgemmParams& p, int dtype, hipStream_t stream) {
   if (p.mode == MODE_SHUFFLE) UNETDC_REQUIRE(p.shuf_c % 64 == 0, "igemm: convT channels must be a multiple of 64");
   if (p.mode == MODE_STATS) UNETDC_REQUIRE(p.stats != nullptr, "igemm: stats buffer missing");
   if (p.mode == MODE_AFFINE_RELU) UNETDC_REQUIRE(p.scale && p.shift, "igemm: scale/shift missing");
+  if (igemm_choice() == 0 && igemm_halo_supported(p, dtype)) return launch_igemm_halo(p, dtype, stream);
   if (!use_legacy() && igemm_dma_supported(p, dtype)) return launch_igemm_dma(p, dtype, stream);
   const bool wide = (p.Cout % 128 == 0) && p.mode != MODE_STATS;     // statistics rows assume BM = 256
   if (dtype == UNETDC_BF16)
