@@ -87,6 +87,21 @@ def test_conv3x3_fwd_dgrad_wgrad(dtype, case):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 512, 256, 64, 64, 1), (1, 520, 512, 128, 64, 1), (4, 256, 256, 64, 128, 2)])
+def test_wgrad_tap_fused(dtype, case):
+    """>= 256K pixels with a 64-channel side: routed to wgrad_fused.hip (one staging for all 9 taps)."""
+    n, h, w, cin, cout, d = case
+    g = gen(4)
+    x = G.quant(torch.randn(n, cin, h, w, generator=g), dtype)
+    dy = G.quant(torch.randn(n, cout, h, w, generator=g), dtype)
+    wr = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    gw_ref, = torch.autograd.grad(F.conv2d(x, wr, None, padding=d, dilation=d), wr, dy)
+    xv = G.to_nhwc(x, dtype, ld=cin + 64, off=64)
+    dw = G.conv3x3_wgrad(xv, G.to_nhwc(dy, dtype), n, h, w, cin, cout, d, dtype).cpu()
+    assert rel(dw, gw_ref) < TOL_W[dtype], rel(dw, gw_ref)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_wgrad_many_pixels_ksplit(dtype):
     """K (pixels) large enough that several K-slices and a ragged last slice are exercised."""
     n, h, w, cin, cout, d = 2, 96, 80, 64, 64, 2

@@ -201,15 +201,24 @@ int wgrad_dma_tile(int CI, int CJ);
 int wgrad_dma_pixel_step(int dtype, int tw);
 bool wgrad_dma_supported(const WgradParams& p, int dtype);
 int launch_wgrad_dma_kernel(WgradParams& p, int tw, int dtype, hipStream_t stream);
+// tap-fused kernel for narrow 3x3 layers, wgrad_fused.hip
+bool wgrad_fused_supported(int N, int H, int W, int CI, int CJ, int lda, int ldb, int d, int ntaps, int stride,
+                           int dtype);
+long wgrad_fused_workspace_bytes(int N, int H, int W, int CI, int CJ, int dtype);
+int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* part, int N, int H, int W, int CI,
+                       int CJ, int d, int dtype, int* units_out, hipStream_t stream);
 
-static bool wgrad_legacy() {
+// UNETDC_WGRAD=legacy: first-generation register-staged kernel; =dma: per-tap LDS-DMA kernels only
+// (no tap-fused kernel).  Default: best kernel per layer.
+static int wgrad_choice() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("UNETDC_WGRAD");
-    v = (e && e[0] == 'l') ? 1 : 0;        // UNETDC_WGRAD=legacy: first-generation register-staged kernel
+    v = (e && e[0] == 'l') ? 1 : ((e && e[0] == 'd') ? 2 : 0);
   }
-  return v == 1;
+  return v;
 }
+static bool wgrad_legacy() { return wgrad_choice() == 1; }
 
 static int pixel_step(int dtype, bool wide) {
   const int rb = (wide ? 2 : 1) * 64 * (dtype == UNETDC_BF16 ? 2 : 4);
@@ -288,6 +297,22 @@ int launch_wgrad(WgradParams& p, float* out, void* workspace, long workspace_byt
   const long P = (long)p.N * p.H * p.W;
   UNETDC_REQUIRE(P > 0 && P < (1L << 31) - 4096, "wgrad: pixel count out of range");
   p.P = (int)P;
+  if (wgrad_choice() == 0 && p.Hb == p.H && p.Wb == p.W &&
+      wgrad_fused_supported(p.N, p.H, p.W, p.CI, p.CJ, p.lda, p.ldb, p.offy[8], p.ntaps, p.stride, dtype)) {
+    const long need_f = wgrad_fused_workspace_bytes(p.N, p.H, p.W, p.CI, p.CJ, dtype);
+    if (need_f > workspace_bytes) {
+      set_error("wgrad: workspace too small (%ld < %ld bytes)", workspace_bytes, need_f);
+      return UNETDC_EWORKSPACE;
+    }
+    int units = 0;
+    int rc = launch_wgrad_fused(p.a, p.lda, p.b, p.ldb, reinterpret_cast<float*>(workspace), p.N, p.H, p.W, p.CI,
+                                p.CJ, p.offy[8], dtype, &units, stream);
+    if (rc != UNETDC_OK) return rc;
+    const long n = (long)p.CI * p.CJ * p.ntaps;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<float*>(workspace), out, units, p.ntaps, p.CI, p.CJ);
+    return check_launch("wgrad_reduce_kernel");
+  }
   const bool dma = !wgrad_legacy() && wgrad_dma_supported(p, dtype);
   const bool wide = wgrad_wide(p.CI, p.CJ);
   const int tw = dma ? wgrad_dma_tile(p.CI, p.CJ) : (wide ? 2 : 1);

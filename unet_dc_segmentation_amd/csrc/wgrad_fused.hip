@@ -1,0 +1,232 @@
+// Tap-fused weight gradient for the narrow, huge-pixel 3x3 layers (64-channel tiles).
+//
+//   dW[t][co][ci] = sum_p dY[p][co] * X[p + off_t][ci]                (autograd of nn.Conv2d,
+//                                                                     models/model_2.py:41-51)
+// The per-tap kernel (wgrad_dma.hip) re-stages dY and X for each of the 9 taps and, on a 64x64 tile,
+// gets only 8 MFMAs per wave between barriers: it ran at ~370 TFLOP/s on enc1/dec1.  Here one
+// workgroup walks down a vertical strip of the image (SEG pixels wide).  Per image row it stages
+//   * the dY row segment            [SEG pixels][64 co]
+//   * three X row segments y-d,y,y+d [SEG + 2d (padded to SEG+8) pixels][64 ci]   (zero outside)
+// by LDS-DMA and accumulates ALL NINE taps from them: tap (ky,kx) reads X segment ky at pixel rows
+// shifted by kx*d.  9x the MFMA work per staged byte and per barrier.
+// Waves: 2x2 quadrants of the 64x64 (co x ci) tile, 9 accumulators (one per tap) each.
+// Fragments as in wgrad_frag.h: bf16 via ds_read_b64_tr_b16 on the [pixel][channel] image (64-byte
+// units XOR-swizzled by pixel row), fp32 via scalar reads.  Strips x y-ranges give the K split;
+// partial slabs are reduced by wgrad_reduce_kernel (deterministic).
+#include "kernels.h"
+#include "wgrad_frag.h"
+
+namespace unetdc {
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+constexpr unsigned FOOB = 0x80000000u;
+
+struct WgradFusedParams {
+  const void* dy;   // [P][lddy], channels -> i
+  const void* x;    // [P][ldx],  channels -> j
+  float* part;      // [units][9][CI][CJ]
+  int N, H, W, CI, CJ, lddy, ldx, d;
+  int ysplit, rows_per_unit, itiles, jtiles;
+};
+
+template <typename T> struct FusedCfg;
+template <> struct FusedCfg<bf16_t> { static constexpr int SEG = 64; };
+template <> struct FusedCfg<float> { static constexpr int SEG = 32; };
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void wgrad_fused_kernel(const WgradFusedParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int SEG = FusedCfg<T>::SEG;
+  constexpr int XR = SEG + 8;                          // X segment rows (x0-d .. x0+SEG-1+d, d <= 4)
+  constexpr int ES = (int)sizeof(T);
+  constexpr int RB = 64 * ES;                          // bytes per pixel row (64 channels)
+  constexpr int CPR = RB / 16, RPI = 64 / CPR;         // lanes per row, rows per DMA instruction
+  constexpr int DYI = SEG / RPI, XI = XR / RPI;        // DMA instructions: dY segment, one X segment
+  constexpr int NSLOT = (DYI + 3 * XI + 3) / 4;        // per wave
+  constexpr int DYB = SEG * RB, XB = XR * RB;
+  constexpr int STAGE = DYB + 3 * XB;
+  static_assert(SEG % RPI == 0 && XR % RPI == 0, "segment/instruction mismatch");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qi = wave >> 1, qj = wave & 1;
+  // block -> (unit, it, jt); unit -> (image, x segment, y range)
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles = p.itiles * p.jtiles;
+  const int unit = L / tiles, trem = L - unit * tiles;
+  const int it = trem / p.jtiles, jt = trem - it * p.jtiles;
+  const int i0 = it * 64, j0 = jt * 64;
+  const int segs = p.W / SEG;
+  const int ys = unit % p.ysplit, strip = unit / p.ysplit;
+  const int n = strip / segs, x0 = (strip - n * segs) * SEG;
+  const int ybeg = ys * p.rows_per_unit;
+  const int yend = min(ybeg + p.rows_per_unit, p.H);
+
+  const unsigned dybytes = (unsigned)((long)p.N * p.H * p.W * p.lddy * ES);
+  const unsigned xbytes = (unsigned)((long)p.N * p.H * p.W * p.ldx * ES);
+  const __amdgpu_buffer_rsrc_t dyr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, dybytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, xbytes, 0x00020000);
+
+  // ---- DMA slots of this wave: slot q -> global instruction index gi = wave + 4*q --------------
+  //   gi < DYI            : dY segment, instruction gi
+  //   gi = DYI + ky*XI + k: X segment ky, instruction k
+  const int sub = lane / CPR, pc = lane % CPR;
+  unsigned colb[NSLOT];          // byte offset inside the image row (pixel * ld + channel chunk) or FOOB
+#pragma unroll
+  for (int q = 0; q < NSLOT; ++q) {
+    const int gi = wave + 4 * q;
+    if (gi < DYI) {
+      const int row = gi * RPI + sub;                                  // pixel x0 + row
+      const int c = Frag<T, 1>::src_chunk(row, pc);
+      colb[q] = (unsigned)(((x0 + row) * p.lddy + i0) * ES + c * 16);
+    } else if (gi < DYI + 3 * XI) {
+      const int k = (gi - DYI) % XI;
+      const int row = k * RPI + sub;                                   // pixel x0 - d + row
+      const int gx = x0 - p.d + row;
+      const int c = Frag<T, 1>::src_chunk(row, pc);
+      colb[q] = ((unsigned)gx < (unsigned)p.W) ? (unsigned)((gx * p.ldx + j0) * ES + c * 16) : FOOB;
+    } else {
+      colb[q] = FOOB;
+    }
+  }
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  auto issue = [&](int stage, int y) {
+    unsigned char* sbase = smem + stage * STAGE;
+#pragma unroll
+    for (int q = 0; q < NSLOT; ++q) {
+      const int gi = wave + 4 * q;                                     // wave-uniform
+      if (gi < DYI) {
+        const unsigned rowbase = (unsigned)((long)(n * p.H + y) * p.W * p.lddy * ES);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(dyr, LDS_PTR(sbase + gi * 1024), 16, rowbase + colb[q], 0, 0, 0);
+      } else if (gi < DYI + 3 * XI) {
+        const int ky = (gi - DYI) / XI, k = (gi - DYI) - ky * XI;
+        const int yy = y + (ky - 1) * p.d;
+        const bool yok = (unsigned)yy < (unsigned)p.H;
+        const unsigned rowbase = (unsigned)((long)(n * p.H + (yok ? yy : 0)) * p.W * p.ldx * ES);
+        const unsigned v = (yok && colb[q] != FOOB) ? rowbase + colb[q] : FOOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, LDS_PTR(sbase + DYB + ky * XB + k * 1024), 16, v, 0, 0, 0);
+      }
+    }
+  };
+
+  const int nsteps = yend - ybeg;
+  if (nsteps > 0) issue(0, ybeg);
+  for (int s = 0; s < nsteps; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (s + 1 < nsteps) issue((s + 1) & 1, ybeg + s + 1);
+    const unsigned char* sdy = smem + (s & 1) * STAGE;
+    const unsigned char* sx = sdy + DYB;
+#pragma unroll
+    for (int k16 = 0; k16 < SEG / 16; ++k16) {
+      if constexpr (sizeof(T) == 2) {
+        const bf16x8 fa = Frag<bf16_t, 1>::frag(sdy, lane, qi * 32, 16 * k16);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int ky = t / 3, kx = t - ky * 3;
+          const bf16x8 fb = Frag<bf16_t, 1>::frag(sx + ky * XB, lane, qj * 32, 16 * k16 + kx * p.d);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
+        }
+      } else {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int kp = 0; kp < 8; ++kp) {
+          const int krow = 16 * k16 + 2 * kp + h;
+          const float fa = *reinterpret_cast<const float*>(sdy + krow * RB + (qi * 32 + r) * 4);
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t - ky * 3;
+            const float fb = *reinterpret_cast<const float*>(sx + ky * XB + (krow + kx * p.d) * RB + (qj * 32 + r) * 4);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- partial slab: part[unit][t][i][j] ---------------------------------------------------------
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float* slab = p.part + ((long)unit * 9 + t) * p.CI * p.CJ;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int i = i0 + qi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h, j = j0 + qj * 32 + r;
+      slab[(long)i * p.CJ + j] = acc[t][reg];
+    }
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+// ------------------------------------------------------------------------------------------------
+static int fused_seg(int dtype) { return dtype == UNETDC_BF16 ? 64 : 32; }
+
+bool wgrad_fused_supported(int N, int H, int W, int CI, int CJ, int lda, int ldb, int d, int ntaps, int stride,
+                           int dtype) {
+  if (ntaps != 9 || stride != 1 || d < 1 || d > 4) return false;
+  if (CI % 64 != 0 || CJ % 64 != 0) return false;
+  if (!(CI <= 128 && CJ <= 128 && (CI == 64 || CJ == 64))) return false;     // narrow layers only
+  if (W % fused_seg(dtype) != 0) return false;
+  const long P = (long)N * H * W;
+  if (P < 256L * 1024) return false;
+  const long es = dtype == UNETDC_BF16 ? 2 : 4;
+  return P * lda * es < (1L << 31) && P * ldb * es < (1L << 31);
+}
+
+static void fused_plan(int N, int H, int W, int CI, int CJ, int dtype, int& ysplit, int& rows) {
+  const int strips = N * (W / fused_seg(dtype));
+  const int tiles = (CI / 64) * (CJ / 64);
+  int ys = 512 / (strips * tiles);                 // ~2 workgroups per CU
+  if (ys < 1) ys = 1;
+  if (ys > H / 8) ys = H / 8 > 0 ? H / 8 : 1;
+  rows = (H + ys - 1) / ys;
+  ysplit = (H + rows - 1) / rows;
+}
+
+long wgrad_fused_workspace_bytes(int N, int H, int W, int CI, int CJ, int dtype) {
+  int ys, rows;
+  fused_plan(N, H, W, CI, CJ, dtype, ys, rows);
+  return (long)N * (W / fused_seg(dtype)) * ys * 9 * CI * CJ * 4;
+}
+
+// Fills the slabs; the caller reduces `units` slabs with wgrad_reduce_kernel.
+int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* part, int N, int H, int W, int CI,
+                       int CJ, int d, int dtype, int* units_out, hipStream_t stream) {
+  WgradFusedParams p{};
+  p.dy = dy; p.x = x; p.part = part; p.N = N; p.H = H; p.W = W; p.CI = CI; p.CJ = CJ; p.lddy = lddy; p.ldx = ldx;
+  p.d = d;
+  fused_plan(N, H, W, CI, CJ, dtype, p.ysplit, p.rows_per_unit);
+  p.itiles = CI / 64;
+  p.jtiles = CJ / 64;
+  const int units = N * (W / fused_seg(dtype)) * p.ysplit;
+  *units_out = units;
+  const long nwg = (long)units * p.itiles * p.jtiles;
+  const int es = dtype == UNETDC_BF16 ? 2 : 4;
+  const int seg = fused_seg(dtype);
+  const int lds = 2 * (seg * 64 * es + 3 * (seg + 8) * 64 * es);
+  static bool attr_done[2] = {false, false};
+  const void* fn = dtype == UNETDC_BF16 ? reinterpret_cast<const void*>(&wgrad_fused_kernel<bf16_t>)
+                                        : reinterpret_cast<const void*>(&wgrad_fused_kernel<float>);
+  if (!attr_done[dtype]) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(wgrad_fused_kernel) failed: %s", hipGetErrorString(e));
+      return UNETDC_ELAUNCH;
+    }
+    attr_done[dtype] = true;
+  }
+  if (dtype == UNETDC_BF16)
+    hipLaunchKernelGGL(wgrad_fused_kernel<bf16_t>, dim3((unsigned)nwg), dim3(256), lds, stream, p);
+  else
+    hipLaunchKernelGGL(wgrad_fused_kernel<float>, dim3((unsigned)nwg), dim3(256), lds, stream, p);
+  return check_launch("wgrad_fused_kernel");
+}
+
+}  // namespace unetdc
