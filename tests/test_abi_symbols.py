@@ -51,7 +51,7 @@ def test_host_only_queries_and_error_reporting(lib):
     assert lib.unetdc_version() == 1
     # pure host-side planning queries (no device needed)
     assert lib.unetdc_conv3x3_stats_rows(8 * 512 * 512, 64) == 8192
-    assert lib.unetdc_conv3x3_stats_rows(8 * 32 * 32, 1024) == 64
+    assert lib.unetdc_conv3x3_stats_rows(8 * 32 * 32, 1024) == 32
     assert lib.unetdc_conv3x3_wgrad_workspace(8, 512, 512, 64, 64, 1) > 0
     assert lib.unetdc_bn_relu_bwd_workspace(8, 512, 512, 64, 1, 1) > 0
     # argument validation happens before any HIP call: bad shapes give a negative code + message

@@ -84,7 +84,7 @@ int unetdc_conv3x3_dgrad(const void* dy, int lddy, const void* w_dgrad, void* dx
 
 int64_t unetdc_conv3x3_wgrad_workspace(int n, int h, int w, int cin, int cout, int dtype) {
   long b = wgrad_workspace_bytes((long)n * h * w, cout, cin, 9, dtype);
-  if (w % 64 == 0 && h >= 8) {          // the tap-fused kernel may be chosen for narrow layers
+  if (w % 32 == 0 && h >= 8) {          // the tap-fused kernel may be chosen
     const long f = wgrad_fused_workspace_bytes(n, h, w, cout, cin, dtype);
     if (f > b) b = f;
   }

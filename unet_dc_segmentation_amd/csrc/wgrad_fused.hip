@@ -1,4 +1,4 @@
-// Tap-fused weight gradient for the narrow, huge-pixel 3x3 layers (64-channel tiles).
+// Tap-fused weight gradient of the dilated 3x3 convolutions (64x64 channel tiles, d <= 8).
 //
 //   dW[t][co][ci] = sum_p dY[p][co] * X[p + off_t][ci]                (autograd of nn.Conv2d,
 //                                                                     models/model_2.py:41-51)
@@ -6,13 +6,15 @@
 // gets only 8 MFMAs per wave between barriers: it ran at ~370 TFLOP/s on enc1/dec1.  Here one
 // workgroup walks down a vertical strip of the image (SEG pixels wide).  Per image row it stages
 //   * the dY row segment            [SEG pixels][64 co]
-//   * three X row segments y-d,y,y+d [SEG + 2d (padded to SEG+8) pixels][64 ci]   (zero outside)
+//   * three X row segments y-d,y,y+d [SEG + 2d (padded to SEG+16) pixels][64 ci]  (zero outside)
 // by LDS-DMA and accumulates ALL NINE taps from them: tap (ky,kx) reads X segment ky at pixel rows
 // shifted by kx*d.  9x the MFMA work per staged byte and per barrier.
 // Waves: 2x2 quadrants of the 64x64 (co x ci) tile, 9 accumulators (one per tap) each.
 // Fragments as in wgrad_frag.h: bf16 via ds_read_b64_tr_b16 on the [pixel][channel] image (64-byte
 // units XOR-swizzled by pixel row), fp32 via scalar reads.  Strips x y-ranges give the K split;
 // partial slabs are reduced by wgrad_reduce_kernel (deterministic).
+#include <stdlib.h>
+
 #include "kernels.h"
 #include "wgrad_frag.h"
 
@@ -37,7 +39,7 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void wgrad_fused_kernel(const WgradFusedParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int SEG = FusedCfg<T>::SEG;
-  constexpr int XR = SEG + 8;                          // X segment rows (x0-d .. x0+SEG-1+d, d <= 4)
+  constexpr int XR = SEG + 16;                         // X segment rows (x0-d .. x0+SEG-1+d, d <= 8)
   constexpr int ES = (int)sizeof(T);
   constexpr int RB = 64 * ES;                          // bytes per pixel row (64 channels)
   constexpr int CPR = RB / 16, RPI = 64 / CPR;         // lanes per row, rows per DMA instruction
@@ -170,12 +172,25 @@ static int fused_seg(int dtype) { return dtype == UNETDC_BF16 ? 64 : 32; }
 
 bool wgrad_fused_supported(int N, int H, int W, int CI, int CJ, int lda, int ldb, int d, int ntaps, int stride,
                            int dtype) {
-  if (ntaps != 9 || stride != 1 || d < 1 || d > 4) return false;
+  if (ntaps != 9 || stride != 1 || d < 1 || d > 8) return false;
   if (CI % 64 != 0 || CJ % 64 != 0) return false;
-  if (!(CI <= 128 && CJ <= 128 && (CI == 64 || CJ == 64))) return false;     // narrow layers only
+  static int maxc = -1, need64 = -1;
+  if (maxc < 0) {
+    const char* e = getenv("UNETDC_FUSED_MAXC");
+    maxc = e ? atoi(e) : 1024;
+    const char* f = getenv("UNETDC_FUSED_NEED64");
+    need64 = f ? atoi(f) : 0;
+  }
+  if (CI > maxc || CJ > maxc) return false;
+  if (need64 && !(CI == 64 || CJ == 64)) return false;                       // narrow layers only
   if (W % fused_seg(dtype) != 0) return false;
   const long P = (long)N * H * W;
-  if (P < 256L * 1024) return false;
+  static long minp = -1;
+  if (minp < 0) {
+    const char* e = getenv("UNETDC_FUSED_MINP");
+    minp = e ? atol(e) : 32L * 1024;
+  }
+  if (P < minp) return false;
   const long es = dtype == UNETDC_BF16 ? 2 : 4;
   return P * lda * es < (1L << 31) && P * ldb * es < (1L << 31);
 }
@@ -191,6 +206,7 @@ static void fused_plan(int N, int H, int W, int CI, int CJ, int dtype, int& yspl
 }
 
 long wgrad_fused_workspace_bytes(int N, int H, int W, int CI, int CJ, int dtype) {
+  if (W < fused_seg(dtype) || W % fused_seg(dtype) != 0 || H < 1 || CI % 64 != 0 || CJ % 64 != 0) return 0;
   int ys, rows;
   fused_plan(N, H, W, CI, CJ, dtype, ys, rows);
   return (long)N * (W / fused_seg(dtype)) * ys * 9 * CI * CJ * 4;
@@ -210,7 +226,7 @@ int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* 
   const long nwg = (long)units * p.itiles * p.jtiles;
   const int es = dtype == UNETDC_BF16 ? 2 : 4;
   const int seg = fused_seg(dtype);
-  const int lds = 2 * (seg * 64 * es + 3 * (seg + 8) * 64 * es);
+  const int lds = 2 * (seg * 64 * es + 3 * (seg + 16) * 64 * es);
   static bool attr_done[2] = {false, false};
   const void* fn = dtype == UNETDC_BF16 ? reinterpret_cast<const void*>(&wgrad_fused_kernel<bf16_t>)
                                         : reinterpret_cast<const void*>(&wgrad_fused_kernel<float>);
