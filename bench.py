@@ -51,21 +51,41 @@ def synthetic_batch(seed, n, h, w, cin=1, discs=200):
     return torch.from_numpy(x), torch.from_numpy(t)
 
 
-def igemm_flops(name, a):
-    """Nominal dense FLOPs (padded taps included) of one implicit-GEMM launch from its C-ABI args."""
+def igemm_flops(name, a, es=2):
+    """(nominal dense FLOPs incl. padded taps, algorithmic bytes = input + weights + output read/written
+    once) of one implicit-GEMM launch, from its C-ABI arguments."""
     if name == "unetdc_conv3x3_fwd":
         n, h, w, cin, cout = a[9:14]
-        return 2.0 * n * h * w * cout * cin * 9, cout
+        return 2.0 * n * h * w * cout * cin * 9, (n * h * w * (cin + cout) + 9 * cin * cout) * es
     if name == "unetdc_conv3x3_dgrad":
         n, h, w, cin, cout = a[5:10]
-        return 2.0 * n * h * w * cout * cin * 9, cin
+        return 2.0 * n * h * w * cout * cin * 9, (n * h * w * (cin + cout) + 9 * cin * cout) * es
     if name == "unetdc_convT2x2_fwd":
         n, h, w, cin, cout = a[6:11]
-        return 2.0 * n * h * w * cin * 4 * cout, 4 * cout
+        return 2.0 * n * h * w * cin * 4 * cout, (n * h * w * (cin + 4 * cout) + 4 * cin * cout) * es
     if name == "unetdc_convT2x2_dgrad":
         n, h, w, cin, cout = a[5:10]
-        return 2.0 * n * h * w * cin * 4 * cout, cin
+        return 2.0 * n * h * w * cin * 4 * cout, (n * h * w * (cin + 4 * cout) + 4 * cin * cout) * es
     raise KeyError(name)
+
+
+def pmc_traffic(kernel):
+    """Per-launch bytes past the L2 for `kernel` from the committed rocprofv3 PMC summary (separate
+    FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 correction on the read side) or None."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        table = json.load(open(path))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    # rocprofv3 prints Itanium-mangled names for the __bf16 instantiations (c++filt cannot demangle
+    # DF16b), e.g. igemm_dma_kernel<__bf16, 2, 4, 4> -> igemm_dma_kernelIDF16bLi2ELi4ELi4EE
+    base, _, targs = kernel.partition("<")
+    frag = base + "I" + "".join("DF16b" if a.strip() == "__bf16" else ("f" if a.strip() == "float" else f"Li{a.strip()}E")
+                                for a in targs.rstrip(">").split(",")) + "E"
+    for sym, v in table.items():
+        if frag in sym or kernel in sym:
+            return v["bytes_corrected"]
+    return None
 
 
 def host_cores():
@@ -93,7 +113,8 @@ def per_layer_table(step, args):
     per = len(rec) // 3
     rows = rec[2 * per:]
     tot = {}
-    for name, a, ms in rows:
+    for tagged, a, ms in rows:
+        name = tagged.split("|")[0]
         fl, shape = 0.0, ""
         ints = [v for v in a if isinstance(v, int) and 0 < v < 100000]
         if name in ("unetdc_conv3x3_fwd", "unetdc_conv3x3_dgrad", "unetdc_convT2x2_fwd", "unetdc_convT2x2_dgrad"):
@@ -148,6 +169,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--per-layer", action="store_true", help="print a per-call timing table to stderr (diagnostic)")
+    ap.add_argument("--mode", default="train", choices=["train", "infer"],
+                    help="train = the headline metric (default); infer = forward-only eval (BASELINE configs[1])")
     args = ap.parse_args()
 
     from unet_dc_segmentation_amd import _lib, dp as dpmod
@@ -172,13 +195,22 @@ def main():
     x, t = synthetic_batch(1000 + rank, args.batch, args.size, args.size, args.in_channels)
     x, t = x.to(dev), t.to(dev)
 
-    def step():
+    def train_step():
         opt.zero_grad(set_to_none=True)
         p = model(x)
         loss = focal_dice_loss(p, t, alpha=1.0, gamma=2.0, ratio=0.3)      # train_DC_focal.py:222
         loss.backward()
         opt.step()
         return loss
+
+    def infer_step():                                      # quantify_droplets_batch.py:51-56 on device
+        with torch.no_grad():
+            p = model(x)
+            return (p > 0.3).sum()
+
+    if args.mode == "infer":
+        model.eval()
+    step = train_step if args.mode == "train" else infer_step
 
     for _ in range(args.warmup):
         step()
@@ -206,45 +238,53 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel -------------------------------------------------
         groups = {}
-        for name, a, ms in records:
-            fl, ncols = igemm_flops(name, a)
-            key = "igemm_conv_kernel<%s,2,2>" % args.dtype if ncols % 128 == 0 else "igemm_conv_kernel<%s,4,1>" % args.dtype
-            gsum = groups.setdefault(key, [0.0, 0.0, 0])
+        for tagged, a, ms in records:
+            name, key = tagged.split("|")              # C-ABI entry point | dispatched kernel symbol
+            fl, nbytes = igemm_flops(name, a, 2 if args.dtype == "bf16" else 4)
+            gsum = groups.setdefault(key, [0.0, 0.0, 0, 0.0])
             gsum[0] += fl
             gsum[1] += ms
             gsum[2] += 1
+            gsum[3] += nbytes
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         kernels = []
-        for key, (fl, ms, cnt) in groups.items():
+        for key, (fl, ms, cnt, nbytes) in groups.items():
             kernels.append({"kernel": key, "launches_per_step": cnt / args.steps, "avg_launch_ms": ms / cnt,
                             "gflop_per_launch": fl / cnt / 1e9, "tflops": fl / (ms * 1e-3) / 1e12,
-                            "ms_per_step": ms / args.steps})
+                            "ms_per_step": ms / args.steps, "algorithmic_bytes_per_launch": nbytes / cnt})
         kernels.sort(key=lambda k: -k["ms_per_step"])
         dom = kernels[0]
         roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak,
-                    "unit": "TFLOP/s", "frac": dom["tflops"] / peak, "traffic": None,
+                    "unit": "TFLOP/s", "frac": dom["tflops"] / peak,
+                    "traffic": pmc_traffic(dom["kernel"]) if args.mode == "train" and args.dtype == "bf16" else None,
+                    "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
                     "flop_per_launch": dom["gflop_per_launch"] * 1e9, "avg_launch_ms": dom["avg_launch_ms"],
                     "launches_per_step": dom["launches_per_step"], "all_igemm_kernels": kernels}
-        nominal_gflop_img = 1153.9 if (args.size == 512 and args.in_channels == 1) else None
+        nominal_gflop_img = ((1153.9 if args.mode == "train" else 384.74)
+                             if (args.size == 512 and args.in_channels == 1) else None)
         imgs = args.batch * world * args.steps
         out = {
-            "metric": "images/sec fwd+bwd, 512x512x1 U-Net-DC, bs=8/GPU",
+            "metric": "images/sec fwd+bwd, 512x512x1 U-Net-DC, bs=8/GPU" if args.mode == "train"
+                      else "images/sec forward-only inference, 512x512x1 U-Net-DC, bs=8/GPU",
             "value": imgs / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"train step (fwd + Focal/Dice loss + bwd + Adam{' + RCCL grad all-reduce' if world > 1 else ''}) "
-                                   f"{args.arch} bs={args.batch}/GPU {args.size}x{args.size}x{args.in_channels} "
-                                   "(BASELINE configs[2]/[3])",
+            "config": {"workload": (f"train step (fwd + Focal/Dice loss + bwd + Adam{' + RCCL grad all-reduce' if world > 1 else ''}) "
+                                    f"{args.arch} bs={args.batch}/GPU {args.size}x{args.size}x{args.in_channels} "
+                                    "(BASELINE configs[2]/[3])") if args.mode == "train" else
+                                   (f"eval forward + 0.3 threshold, {args.arch} bs={args.batch}/GPU "
+                                    f"{args.size}x{args.size}x{args.in_channels} (BASELINE configs[1])"),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "timed_region": "zero_grad, model(x), focal_dice_loss, backward, all-reduce, Adam step, weight re-pack"},
+                       "timed_region": "zero_grad, model(x), focal_dice_loss, backward, all-reduce, Adam step, weight re-pack"
+                                       if args.mode == "train" else "model(x) under no_grad + threshold, input resident in HBM"},
             "roofline": roofline,
-            "final_loss": final_loss,
+            "final_value": final_loss,
         }
         if nominal_gflop_img:
             out["whole_step_tflops_nominal"] = nominal_gflop_img * 1e9 * imgs / elapsed / 1e12
         if wrapper is not None:
             out["allreduce_buckets_per_step"] = wrapper.stats["buckets"] / (args.steps + args.warmup)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.mode == "train":
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.size, args.size, args.in_channels)
         print(json.dumps(out), flush=True)
     if world > 1:

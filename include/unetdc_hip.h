@@ -44,6 +44,9 @@ typedef void* unetdc_stream_t; /* hipStream_t */
 
 int unetdc_version(void);
 const char* unetdc_last_error(void);
+/* symbol (as rocprofv3 prints it) of the matrix-core kernel the last conv/convT/wgrad call dispatched;
+ * the library picks the kernel per layer shape, profiling tools use this to attribute time. */
+const char* unetdc_last_kernel(void);
 
 /* ---- weight packing (derived caches of the fp32 parameters; redo after optimizer.step()) ------
  * conv3x3:  w [Cout][Cin][3][3] -> w_fwd [9][Cout][Cin], w_dgrad [9][Cin][Cout] (taps flipped)

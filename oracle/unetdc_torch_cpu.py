@@ -21,31 +21,57 @@ DILATIONS_DC = {"enc1": 1, "enc2": 2, "enc3": 4, "enc4": 8, "bottleneck": 16,
 DILATIONS_PLAIN = {b: 1 for b in BLOCKS}                              # models/model.py:25-33
 
 
-def _double_conv(x, sd, name, d, train, momentum=0.1, eps=1e-5):
+class _StoreBF16(torch.autograd.Function):
+    """Round a tensor through bfloat16 storage (straight-through gradient).  Used to emulate the HIP
+    path's bf16 configuration -- bf16 weights / conv outputs / activations, fp32 accumulation and
+    fp32 BatchNorm arithmetic -- on top of the fp32 ATen ops.  A CPU study shows the
+    forward rounding is what separates bf16 from fp32 gradients at random init (cosine ~0.90 in the
+    deepest layers); rounding the stored gradients is invisible (cosine 1.0000)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _q(x, emulate_bf16):
+    return _StoreBF16.apply(x) if emulate_bf16 else x
+
+
+def _double_conv(x, sd, name, d, train, momentum=0.1, eps=1e-5, emulate_bf16=False):
     """double_conv (model_2.py:34-54): (Conv3x3 pad=d dil=d -> BN -> ReLU) x 2."""
     for idx in (0, 3):
-        x = F.conv2d(x, sd[f"{name}.{idx}.weight"], sd[f"{name}.{idx}.bias"], padding=d, dilation=d)
+        w = sd[f"{name}.{idx}.weight"]
+        if not (idx == 0 and w.shape[1] < 8):          # the first layer keeps fp32 weights and input
+            w = _q(w, emulate_bf16)
+        x = _q(F.conv2d(x, w, sd[f"{name}.{idx}.bias"], padding=d, dilation=d), emulate_bf16)
         x = F.batch_norm(x, sd[f"{name}.{idx + 1}.running_mean"], sd[f"{name}.{idx + 1}.running_var"],
                          sd[f"{name}.{idx + 1}.weight"], sd[f"{name}.{idx + 1}.bias"],
                          training=train, momentum=momentum, eps=eps)
-        x = F.relu(x)
+        x = _q(F.relu(x), emulate_bf16)
     return x
 
 
-def unet_forward(x, sd, dilations=None, train=False, return_logits=False):
+def unet_forward(x, sd, dilations=None, train=False, return_logits=False, emulate_bf16=False):
     """UNetDC.forward (model_2.py:56-80). ``sd`` maps the 136 reference keys to CPU tensors;
-    in train mode the running_mean/var tensors are updated in place like nn.BatchNorm2d does."""
+    in train mode the running_mean/var tensors are updated in place like nn.BatchNorm2d does.
+    ``emulate_bf16`` rounds weights / conv outputs / activations through bf16 storage (see _StoreBF16)."""
     dil = DILATIONS_DC if dilations is None else dilations
     skips = []
     h = x
     for name in ("enc1", "enc2", "enc3", "enc4"):
-        h = _double_conv(h, sd, name, dil[name], train)
+        h = _double_conv(h, sd, name, dil[name], train, emulate_bf16=emulate_bf16)
         skips.append(h)
         h = F.max_pool2d(h, 2)
-    h = _double_conv(h, sd, "bottleneck", dil["bottleneck"], train)
+    h = _double_conv(h, sd, "bottleneck", dil["bottleneck"], train, emulate_bf16=emulate_bf16)
     for lvl in (4, 3, 2, 1):
-        up = F.conv_transpose2d(h, sd[f"upconv{lvl}.weight"], sd[f"upconv{lvl}.bias"], stride=2)
-        h = _double_conv(torch.cat([up, skips[lvl - 1]], dim=1), sd, f"dec{lvl}", dil[f"dec{lvl}"], train)
+        up = _q(F.conv_transpose2d(h, _q(sd[f"upconv{lvl}.weight"], emulate_bf16), sd[f"upconv{lvl}.bias"], stride=2),
+                emulate_bf16)
+        h = _double_conv(torch.cat([up, skips[lvl - 1]], dim=1), sd, f"dec{lvl}", dil[f"dec{lvl}"], train,
+                         emulate_bf16=emulate_bf16)
     z = F.conv2d(h, sd["out_conv.weight"], sd["out_conv.bias"])
     p = torch.sigmoid(z)
     return (p, z) if return_logits else p
@@ -75,12 +101,12 @@ def param_keys(sd):
                                   or k.endswith("num_batches_tracked"))]
 
 
-def train_step_grads(x, target, sd, dilations=None):
+def train_step_grads(x, target, sd, dilations=None, emulate_bf16=False):
     """fwd (train mode) + focal_dice_loss + backward (train_DC_focal.py:252-254).
     Returns (loss, probs, {key: grad})."""
     keys = param_keys(sd)
     leaf = {k: (sd[k].detach().clone().requires_grad_(True) if k in keys else sd[k]) for k in sd}
-    p = unet_forward(x, leaf, dilations, train=True)
+    p = unet_forward(x, leaf, dilations, train=True, emulate_bf16=emulate_bf16)
     loss = focal_dice_loss(p, target, 1.0, 2.0, 0.3)     # train_DC_focal.py:222
     gs = torch.autograd.grad(loss, [leaf[k] for k in keys])
     return loss.detach(), p.detach(), dict(zip(keys, gs))

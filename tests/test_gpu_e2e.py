@@ -107,21 +107,26 @@ def test_bf16_path_close_to_reference(tag):
     cpu_model, _ = build_model(tag, "train")
     sd = {k: v.detach().clone() for k, v in cpu_model.state_dict().items()}
     loss_ref, p_ref, g32 = otc.train_step_grads(xc, tc, sd, dict(cpu_model.DILATIONS))
+    sd = {k: v.detach().clone() for k, v in cpu_model.state_dict().items()}
+    loss_emu, p_emu, gemu = otc.train_step_grads(xc, tc, sd, dict(cpu_model.DILATIONS), emulate_bf16=True)
     assert abs(loss.item() - float(loss_ref)) < 2e-2 * float(loss_ref)
-    assert float((p.detach().cpu() - p_ref).abs().max()) < 6e-2
-    # Gradient direction per weight tensor.  Encoder weight gradients are sums over all pixels of
-    # strongly cancelling terms, so the 2^-9 rounding of the bf16-stored gradients shows there
-    # (it shrinks like 1/sqrt(pixels)); decoder/head gradients are well conditioned.
-    cosines = {}
+    assert abs(loss.item() - float(loss_emu)) < 2e-3 * float(loss_emu)
+    assert float((p.detach().cpu() - p_emu).abs().max()) < 2e-2
+    # Gradients: the HIP bf16 path must agree with the bf16-STORAGE emulation of the reference (same
+    # rounding points, fp32 accumulate); against pure fp32 only a loose bound holds because the forward
+    # rounding itself moves deep-layer gradients at random init (oracle/unetdc_torch_cpu.py:_StoreBF16).
+    rows = []
     for k, prm in model.named_parameters():
         assert torch.isfinite(prm.grad).all()
         if prm.numel() < 4096 or k.endswith(".bias"):
             continue
-        a, b = prm.grad.cpu().double().reshape(-1), g32[k].double().reshape(-1)
-        cosines[k] = float(a @ b / (a.norm() * b.norm()))
-    print(f"[{tag}] bf16 gradient cosine vs fp32 CPU: " + ", ".join(f"{k}={v:.4f}" for k, v in cosines.items()))
-    for k, v in cosines.items():
-        assert v > (0.99 if k.startswith(("dec", "out_conv", "upconv1", "upconv2")) else 0.90), (k, v)
+        a = prm.grad.cpu().double().reshape(-1)
+        be, bf = gemu[k].double().reshape(-1), g32[k].double().reshape(-1)
+        rows.append((k, float(a @ be / (a.norm() * be.norm())), float(a @ bf / (a.norm() * bf.norm()))))
+    print(f"[{tag}] bf16 HIP gradient cosine vs (bf16-emulating oracle / fp32 oracle): "
+          + ", ".join(f"{k}={ce:.4f}/{cf:.4f}" for k, ce, cf in rows))
+    for k, ce, cf in rows:
+        assert ce > 0.93 and cf > 0.80, (k, ce, cf)
 
 
 def test_full_size_eval_mask_fp32():
@@ -155,6 +160,53 @@ def test_full_size_eval_mask_fp32():
     assert np.all(dist[flips] <= err + 1e-7)
     print(f"[full-size] max|dz|={err:.2e}, {int((~guard).sum())} guard-band pixels of {mask.size}, "
           f"{int(flips.sum())} flips inside the band")
+
+
+def test_full_size_bf16_gradients_vs_bf16_emulating_oracle():
+    """Headline configuration (bs 8, 512x512x1, bf16 storage, fp32 accumulate) on the same batch as
+    two CPU evaluations of the reference: plain fp32, and fp32 with the SAME bf16 storage points
+    (weights / conv outputs / activations; oracle/unetdc_torch_cpu.py:_StoreBF16).
+
+    At random init the deep-layer gradients are ill-conditioned with respect to 1e-3-level
+    perturbations of the activations: the bf16-storage evaluation of the reference itself is only
+    0.90-0.93 cosine from fp32 in enc2..bottleneck, and two bf16 evaluations that differ only in
+    fp32 summation order (which flips ~0.1 % of the bf16 roundings) are 0.96-0.98 from each other.
+    Parity criterion for the bf16 path: (a) loss/probabilities match the bf16-storage oracle tightly,
+    (b) the HIP gradients are as close to fp32 as the bf16-storage oracle is (per tensor, -0.03),
+    (c) HIP vs bf16-storage oracle cosine >= 0.94 everywhere, >= 0.999 in the last decoder block."""
+    from models.model_2 import UNetDC
+    from utils.metrics_DC import focal_dice_loss
+    torch.manual_seed(21)
+    model = UNetDC(1, 1)
+    x = recipe.seeded_input(22, (8, 1, 512, 512))
+    t = recipe.seeded_target(23, (8, 1, 512, 512), frac=0.1)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    loss32, _, g32 = otc.train_step_grads(x, t, sd, dict(model.DILATIONS))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    loss_emu, p_emu, gemu = otc.train_step_grads(x, t, sd, dict(model.DILATIONS), emulate_bf16=True)
+    model = model.cuda().train()
+    model.set_compute_dtype("bf16")
+    p = model(x.cuda())
+    loss = focal_dice_loss(p, t.cuda(), alpha=1.0, gamma=2.0, ratio=0.3)
+    loss.backward()
+    assert abs(loss.item() - float(loss_emu)) < 2e-3 * float(loss_emu)
+    assert abs(loss.item() - float(loss32)) < 1e-2 * float(loss32)
+    assert float((p.detach().cpu() - p_emu).abs().max()) < 3e-2
+
+    def cos(a, b):
+        a, b = a.double().reshape(-1), b.double().reshape(-1)
+        return float(a @ b / (a.norm() * b.norm()))
+    rows = []
+    for k, prm in model.named_parameters():
+        if prm.numel() < 4096 or k.endswith(".bias"):
+            continue
+        g = prm.grad.cpu()
+        rows.append((k, cos(g, gemu[k]), cos(g, g32[k]), cos(gemu[k], g32[k])))
+    print("[full-size bf16] per tensor cos(HIP,bf16-oracle) / cos(HIP,fp32) / cos(bf16-oracle,fp32): "
+          + ", ".join(f"{k}={a:.4f}/{b:.4f}/{c:.4f}" for k, a, b, c in rows))
+    for k, c_he, c_hf, c_ef in rows:
+        assert c_hf >= c_ef - 0.03, (k, c_hf, c_ef)
+        assert c_he > (0.999 if k.startswith("dec1") else 0.94), (k, c_he)
 
 
 def test_full_size_train_step_bf16_properties():

@@ -23,6 +23,7 @@ P, I, L, F = c_void_p, c_int, c_int64, c_float
 SIGNATURES = {
     "unetdc_version": (I, []),
     "unetdc_last_error": (c_char_p, []),
+    "unetdc_last_kernel": (c_char_p, []),
     "unetdc_pack_conv3x3": (I, [P, P, P, I, I, I, P]),
     "unetdc_pack_convT2x2": (I, [P, P, P, I, I, I, P]),
     "unetdc_conv3x3_stats_rows": (I, [L, I]),
@@ -109,7 +110,7 @@ def call(name, *args):
         e0.record()
         rc = getattr(load(), name)(*args)
         e1.record()
-        t["records"].append((name, args, e0, e1))
+        t["records"].append((name + "|" + load().unetdc_last_kernel().decode(), args, e0, e1))
         check(rc, name)
         return
     check(getattr(load(), name)(*args), name)

@@ -17,6 +17,9 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+static thread_local char g_kernel[128] = "";
+void note_kernel(const char* name) { snprintf(g_kernel, sizeof(g_kernel), "%s", name); }
+
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -44,6 +47,7 @@ extern "C" {
 
 int unetdc_version(void) { return UNETDC_ABI_VERSION; }
 const char* unetdc_last_error(void) { return g_err; }
+const char* unetdc_last_kernel(void) { return g_kernel; }
 
 int unetdc_pack_conv3x3(const float* w, void* w_fwd, void* w_dgrad, int cout, int cin, int dtype, unetdc_stream_t s) {
   return launch_pack_conv3x3(w, w_fwd, w_dgrad, cout, cin, dtype, (hipStream_t)s);

@@ -26,6 +26,7 @@ namespace unetdc {
 
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+void note_kernel(const char* name);          // records the symbol of the MFMA kernel just launched
 
 #define UNETDC_REQUIRE(cond, ...)                     \
   do {                                                \

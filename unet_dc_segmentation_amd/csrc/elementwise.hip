@@ -51,17 +51,29 @@ int reduce_parts(const float* parts, int nparts, int L, const float** red_ptr, i
 //   parts[i][0][c] = partial sum, parts[i][1][c] = partial sum of squares
 //   scale = gamma*rstd, shift = beta - mean*scale; running stats use the UNBIASED variance.
 // ================================================================================================
-__global__ void bn_finalize_kernel(const float* __restrict__ parts, int nparts, double count,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                   float momentum, float* running_mean, float* running_var, float* scale,
-                                   float* shift, float* mean_out, float* rstd_out, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// 32 lanes cooperate on one channel (partials summed in fp64, fixed lane order -> deterministic);
+// a serial per-thread loop over the partial rows cost ~17 us per launch in load latency alone.
+__device__ __forceinline__ double lane32_sum(double v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ parts, int nparts, double count,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, float momentum,
+                                                          float* running_mean, float* running_var, float* scale,
+                                                          float* shift, float* mean_out, float* rstd_out, int C) {
+  const int c = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
   if (c >= C) return;
   double s = 0.0, q = 0.0;
-  for (int i = 0; i < nparts; ++i) {
+  for (int i = l; i < nparts; i += 32) {
     s += (double)parts[((long)i * 2 + 0) * C + c];
     q += (double)parts[((long)i * 2 + 1) * C + c];
   }
+  s = lane32_sum(s);
+  q = lane32_sum(q);
+  if (l != 0) return;
   const double mean = s / count;
   double var = q / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -263,18 +275,23 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdParams p) {
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ parts, int nparts, double count,
-                                       const float* __restrict__ gamma, const float* __restrict__ rstd,
-                                       float* dgamma, float* dbeta, float* dbias, float* k1, float* k2, float* k3,
-                                       int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ parts, int nparts,
+                                                              double count, const float* __restrict__ gamma,
+                                                              const float* __restrict__ rstd, float* dgamma,
+                                                              float* dbeta, float* dbias, float* k1, float* k2,
+                                                              float* k3, int C) {
+  const int c = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
   if (c >= C) return;
   double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  for (int i = 0; i < nparts; ++i) {
+  for (int i = l; i < nparts; i += 32) {
     s1 += (double)parts[((long)i * 3 + 0) * C + c];
     s2 += (double)parts[((long)i * 3 + 1) * C + c];
     s3 += (double)parts[((long)i * 3 + 2) * C + c];
   }
+  s1 = lane32_sum(s1);
+  s2 = lane32_sum(s2);
+  s3 = lane32_sum(s3);
+  if (l != 0) return;
   const double a = (double)gamma[c] * (double)rstd[c];
   dgamma[c] = (float)s2;
   dbeta[c] = (float)s1;
@@ -476,7 +493,7 @@ int launch_bn_finalize(const float* parts, int nparts, long count, const float* 
   const float* rp; int rows;
   int rc = reduce_parts(parts, nparts, 2 * C, &rp, &rows, stream);
   if (rc != UNETDC_OK) return rc;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, rp, rows, (double)count, gamma,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, stream, rp, rows, (double)count, gamma,
                      beta, eps, momentum, rm, rv, scale, shift, mean, rstd, C);
   return check_launch("bn_finalize_kernel");
 }
@@ -573,7 +590,7 @@ int launch_bn_bwd(BnBwdParams& p, const float* gamma, float* dgamma, float* dbet
   const float* rp; int rows;
   rc = reduce_parts(parts, nb, 3 * p.C, &rp, &rows, stream);
   if (rc != UNETDC_OK) return rc;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 63) / 64), dim3(64), 0, stream, rp, rows,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 7) / 8), dim3(256), 0, stream, rp, rows,
                      (double)p.N * p.H * p.W, gamma, p.rstd, dgamma, dbeta, dbias, k, k + p.C, k + 2 * p.C, p.C);
   rc = check_launch("bn_bwd_finalize_kernel");
   if (rc != UNETDC_OK) return rc;

@@ -28,6 +28,8 @@
 //     d=16 on a 32x32 map: 5 of 9 taps for most blocks).
 #include <stdlib.h>
 
+#include <stdio.h>
+
 #include "kernels.h"
 
 namespace unetdc {
@@ -311,6 +313,9 @@ static int launch_cfg(IgemmParams& p, hipStream_t stream) {
   p.nblocks = p.Cout / BN;
   const long nwg = (long)p.mblocks * p.nblocks;
   hipLaunchKernelGGL((igemm_conv_kernel<T, WM, WN>), dim3((unsigned)nwg), dim3(256), LDS, stream, p);
+  char nm[96];
+  snprintf(nm, sizeof(nm), "igemm_conv_kernel<%s, %d, %d>", sizeof(T) == 2 ? "__bf16" : "float", WM, WN);
+  note_kernel(nm);
   return check_launch("igemm_conv_kernel");
 }
 

@@ -14,6 +14,8 @@
 //     have to cross L2 -> LDS compared with 128x128.
 // Pipeline: two LDS stages, ONE barrier per K-step:  wait(my DMAs of step s) ; barrier ;
 // issue DMAs of step s+1 into the other stage ; ds_read + MFMA on stage s.
+#include <stdio.h>
+
 #include "kernels.h"
 
 namespace unetdc {
@@ -292,6 +294,9 @@ static int launch_dma_cfg(IgemmParams& p, hipStream_t stream) {
   p.nblocks = p.Cout / BN;
   const long nwg = (long)p.mblocks * p.nblocks;
   hipLaunchKernelGGL((igemm_dma_kernel<T, WM, WN, TM>), dim3((unsigned)nwg), dim3(WM * WN * 64), LDS, stream, p);
+  char nm[96];
+  snprintf(nm, sizeof(nm), "igemm_dma_kernel<%s, %d, %d, %d>", sizeof(T) == 2 ? "__bf16" : "float", WM, WN, TM);
+  note_kernel(nm);
   return check_launch("igemm_dma_kernel");
 }
 

@@ -16,6 +16,8 @@
 //     lane owns two adjacent output channels (same epilogue as igemm_dma.hip);
 //   * epilogues: +bias, +BatchNorm partial statistics (one row per tile = 256 pixels), folded
 //     BN+ReLU (eval).
+#include <stdio.h>
+
 #include "kernels.h"
 
 namespace unetdc {
@@ -281,6 +283,9 @@ static int launch_halo_cfg(IgemmParams& p, int d, hipStream_t stream) {
   p.nblocks = p.Cout / (64 * WN);
   const long nwg = (long)p.mblocks * p.nblocks;
   hipLaunchKernelGGL((igemm_halo_kernel<T, WN>), dim3((unsigned)nwg), dim3(256 * WN), lds, stream, p, d, nbuf);
+  char nm[96];
+  snprintf(nm, sizeof(nm), "igemm_halo_kernel<%s, %d>", sizeof(T) == 2 ? "__bf16" : "float", WN);
+  note_kernel(nm);
   return check_launch("igemm_halo_kernel");
 }
 

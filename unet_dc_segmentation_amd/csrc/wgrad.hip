@@ -22,6 +22,8 @@
 // parameter layout -- no atomics, bitwise reproducible.
 #include <stdlib.h>
 
+#include <stdio.h>
+
 #include "kernels.h"
 #include "wgrad_frag.h"
 
@@ -283,6 +285,9 @@ static int launch_w(WgradParams& p, hipStream_t stream) {
   }
   const long nwg = (long)p.ksplit * p.ntaps * p.itiles * p.jtiles;
   hipLaunchKernelGGL((wgrad_kernel<T, TW>), dim3((unsigned)nwg), dim3(256), 65536, stream, p);
+  char nm[96];
+  snprintf(nm, sizeof(nm), "wgrad_kernel<%s, %d>", sizeof(T) == 2 ? "__bf16" : "float", TW);
+  note_kernel(nm);
   return check_launch("wgrad_kernel");
 }
 

@@ -5,6 +5,8 @@
 // (8 waves, 128x64 per wave) for the wide layers.
 //
 //   part[ks][t][i][j] = sum_{p in slice ks} A[p][i] * B[shift_t(p)][j]      (see wgrad.hip)
+#include <stdio.h>
+
 #include "kernels.h"
 #include "wgrad_frag.h"
 
@@ -185,6 +187,9 @@ static int launch_wd(WgradParams& p, hipStream_t stream) {
   }
   const long nwg = (long)p.ksplit * p.ntaps * p.itiles * p.jtiles;
   hipLaunchKernelGGL((wgrad_dma_kernel<T, TW>), dim3((unsigned)nwg), dim3(NT), LDS, stream, p);
+  char nm[96];
+  snprintf(nm, sizeof(nm), "wgrad_dma_kernel<%s, %d>", sizeof(T) == 2 ? "__bf16" : "float", TW);
+  note_kernel(nm);
   return check_launch("wgrad_dma_kernel");
 }
 

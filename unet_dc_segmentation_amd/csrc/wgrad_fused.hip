@@ -242,6 +242,7 @@ int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* 
     hipLaunchKernelGGL(wgrad_fused_kernel<bf16_t>, dim3((unsigned)nwg), dim3(256), lds, stream, p);
   else
     hipLaunchKernelGGL(wgrad_fused_kernel<float>, dim3((unsigned)nwg), dim3(256), lds, stream, p);
+  note_kernel(dtype == UNETDC_BF16 ? "wgrad_fused_kernel<__bf16>" : "wgrad_fused_kernel<float>");
   return check_launch("wgrad_fused_kernel");
 }
 
