@@ -54,6 +54,20 @@ const char* unetdc_last_kernel(void);
  * w_dgrad may be NULL (inference). */
 int unetdc_pack_conv3x3(const float* w, void* w_fwd, void* w_dgrad, int cout, int cin, int dtype, unetdc_stream_t s);
 int unetdc_pack_convT2x2(const float* w, void* w_fwd, void* w_dgrad, int cin, int cout, int dtype, unetdc_stream_t s);
+/* Every layer in ONE launch (LDS-tiled transpose).  `table_dev` is a DEVICE array of n descriptors
+ * sorted by `begin` = running sum of 32x32 channel tiles ((a/32)*(b/32) per tensor; a, b multiples
+ * of 32); kind 0 = conv3x3 with (a,b) = (cout,cin), kind 1 = convT2x2 with (a,b) = (cin,cout);
+ * `total_tiles` = the grand total.  Same images as the two calls above. */
+typedef struct unetdc_pack_desc {
+  const float* w;
+  void* w_fwd;
+  void* w_dgrad; /* nullable */
+  int64_t begin;
+  int32_t a, b;
+  int32_t kind;
+  int32_t pad;
+} unetdc_pack_desc;
+int unetdc_pack_many(const unetdc_pack_desc* table_dev, int n, int64_t total_tiles, int dtype, unetdc_stream_t s);
 
 /* ---- dilated 3x3 convolution, padding = dilation: nn.Conv2d at models/model_2.py:41-44,48-51 ---
  * y = conv(x) + bias                                  (scale == NULL; training: raw pre-BN output)

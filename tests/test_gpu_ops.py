@@ -298,3 +298,33 @@ def test_argument_errors_are_reported():
     with pytest.raises(_lib.UnetdcError, match="workspace too small"):
         call("unetdc_conv3x3_wgrad", x.data_ptr(), 64, x.data_ptr(), 64, x.data_ptr(), x.data_ptr(), 16,
              1, 8, 8, 64, 64, 1, _lib.F32, G.stream())
+
+
+def test_pack_many_matches_per_layer_packers():
+    """The single-launch tiled packer writes the same images as the per-layer packers."""
+    import numpy as np
+    g = gen(17)
+    convs = [torch.randn(64, 64, 3, 3, generator=g), torch.randn(128, 64, 3, 3, generator=g), torch.randn(64, 256, 3, 3, generator=g)]
+    cts = [torch.randn(128, 64, 2, 2, generator=g), torch.randn(256, 128, 2, 2, generator=g)]
+    for dtype in ("f32", "bf16"):
+        ent = []
+        for wt in convs:
+            wf, wd = G.pack_conv(wt, dtype)
+            ent.append((wt.cuda().contiguous(), wf, wd, wt.shape[0], wt.shape[1], 0))
+        for wt in cts:
+            wf, wd = G.pack_convT(wt, dtype)
+            ent.append((wt.cuda().contiguous(), wf, wd, wt.shape[0], wt.shape[1], 1))
+        dt = np.dtype([("w", "<u8"), ("wf", "<u8"), ("wd", "<u8"), ("begin", "<i8"), ("a", "<i4"), ("b", "<i4"),
+                       ("kind", "<i4"), ("pad", "<i4")])
+        tab = np.zeros(len(ent), dtype=dt)
+        outs, off = [], 0
+        for i, (w, wf, wd, a, b, kind) in enumerate(ent):
+            of, od = torch.zeros_like(wf), torch.zeros_like(wd)
+            outs.append((of, od))
+            tab[i] = (w.data_ptr(), of.data_ptr(), od.data_ptr(), off, a, b, kind, 0)
+            off += (a // 32) * (b // 32)
+        tdev = torch.from_numpy(tab.view(np.uint8).copy()).cuda()
+        call("unetdc_pack_many", tdev.data_ptr(), len(ent), off, G.DT[dtype], G.stream())
+        torch.cuda.synchronize()
+        for (w, wf, wd, *_), (of, od) in zip(ent, outs):
+            assert torch.equal(of, wf) and torch.equal(od, wd)

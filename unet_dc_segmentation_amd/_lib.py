@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must be imported before the CDLL below -- see modul
 
 F32, BF16 = 0, 1
 LIB_NAME = "libunetdc_hip.so"
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+LIB_PATH = os.environ.get("UNETDC_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 P, I, L, F = c_void_p, c_int, c_int64, c_float
 
@@ -26,6 +26,7 @@ SIGNATURES = {
     "unetdc_last_kernel": (c_char_p, []),
     "unetdc_pack_conv3x3": (I, [P, P, P, I, I, I, P]),
     "unetdc_pack_convT2x2": (I, [P, P, P, I, I, I, P]),
+    "unetdc_pack_many": (I, [P, I, L, I, P]),
     "unetdc_conv3x3_stats_rows": (I, [L, I]),
     "unetdc_conv3x3_fwd": (I, [P, I, P, P, P, P, P, I, P, I, I, I, I, I, I, I, P]),
     "unetdc_conv3x3_dgrad": (I, [P, I, P, P, I, I, I, I, I, I, I, I, P]),

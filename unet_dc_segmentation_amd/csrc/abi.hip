@@ -56,6 +56,11 @@ int unetdc_pack_convT2x2(const float* w, void* w_fwd, void* w_dgrad, int cin, in
   return launch_pack_convT2x2(w, w_fwd, w_dgrad, cin, cout, dtype, (hipStream_t)s);
 }
 
+int unetdc_pack_many(const unetdc_pack_desc* table_dev, int n, int64_t total_tiles, int dtype, unetdc_stream_t s) {
+  static_assert(sizeof(unetdc_pack_desc) == 48, "unetdc_pack_desc layout");
+  return launch_pack_many(table_dev, n, (long)total_tiles, dtype, (hipStream_t)s);
+}
+
 int unetdc_conv3x3_stats_rows(int64_t npixels, int cout) { return igemm_mblocks((long)npixels, cout); }
 
 int unetdc_conv3x3_fwd(const void* x, int ldx, const void* w_fwd, const float* bias, const float* scale,

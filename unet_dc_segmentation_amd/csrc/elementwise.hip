@@ -475,6 +475,63 @@ __global__ void pack_convT2x2_kernel(const float* __restrict__ w, T* __restrict_
   }
 }
 
+// All layers in ONE launch, as an LDS-tiled transpose: a device-resident table describes each tensor
+// (21 per network); one workgroup handles a 32 x 32 (out x in) channel tile with all its taps, reads
+// the fp32 parameter in contiguous 1152/512-byte rows and writes both K-contiguous images in >= 64-byte
+// runs.  (Element-wise scattering of the transposed dgrad image cost 0.3 ms per step.)
+struct PackDesc {
+  const float* w;      // fp32 parameter, PyTorch layout
+  void* wf;            // forward image
+  void* wd;            // dgrad image (nullable)
+  long begin;          // index of this tensor's first 32x32 tile in the launch
+  int a, b;            // conv3x3: (Cout, Cin), taps 9;  convT: (Cin, Cout), taps 4
+  int kind;            // 0 = conv3x3, 1 = convT2x2
+  int pad;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_many_kernel(const PackDesc* __restrict__ table, int n) {
+  __shared__ float tile[32 * 289];
+  const int tid = threadIdx.x;
+  const long tix = blockIdx.x;
+  int lo = 0, hi = n - 1;                      // last descriptor with begin <= tix
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].begin <= tix) lo = mid; else hi = mid - 1;
+  }
+  const PackDesc d = table[lo];
+  const int local = (int)(tix - d.begin);
+  T* wf = reinterpret_cast<T*>(d.wf);
+  T* wd = reinterpret_cast<T*>(d.wd);
+  if (d.kind == 0) {
+    const int Co = d.a, Ci = d.b, tci = Ci / 32;
+    const int co0 = (local / tci) * 32, ci0 = (local % tci) * 32;
+    for (int i = tid; i < 32 * 288; i += 256) {            // w[co][ci0 .. ci0+31][9]: 288 contiguous floats
+      const int co = i / 288, rem = i - co * 288;
+      tile[co * 289 + rem] = d.w[((long)(co0 + co) * Ci + ci0) * 9 + rem];
+    }
+    __syncthreads();
+    for (int i = tid; i < 9 * 1024; i += 256) {
+      const int t = i >> 10, x = (i >> 5) & 31, y = i & 31;
+      wf[((long)t * Co + co0 + x) * Ci + ci0 + y] = from_f32<T>(tile[x * 289 + y * 9 + t]);            // x = co, y = ci
+      if (wd) wd[((long)(8 - t) * Ci + ci0 + x) * Co + co0 + y] = from_f32<T>(tile[y * 289 + x * 9 + t]);  // x = ci, y = co
+    }
+  } else {
+    const int Ci = d.a, Co = d.b, tco = Co / 32;
+    const int ci0 = (local / tco) * 32, co0 = (local % tco) * 32;
+    for (int i = tid; i < 32 * 128; i += 256) {            // w[ci][co0 .. co0+31][4]: 128 contiguous floats
+      const int ci = i >> 7, rem = i & 127;
+      tile[ci * 129 + rem] = d.w[((long)(ci0 + ci) * Co + co0) * 4 + rem];
+    }
+    __syncthreads();
+    for (int i = tid; i < 4 * 1024; i += 256) {
+      const int ab = i >> 10, x = (i >> 5) & 31, y = i & 31;
+      wf[((long)ab * Co + co0 + x) * Ci + ci0 + y] = from_f32<T>(tile[y * 129 + x * 4 + ab]);              // x = co, y = ci
+      if (wd) wd[((long)ab * Ci + ci0 + x) * Co + co0 + y] = from_f32<T>(tile[x * 129 + y * 4 + ab]);        // x = ci, y = co
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
@@ -717,6 +774,17 @@ int launch_channel_sum(const void* x, int ldx, float* out, void* workspace, long
   if (rc != UNETDC_OK) return rc;
   hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, rp, rows, out, C);
   return check_launch("channel_sum_finalize_kernel");
+}
+
+int launch_pack_many(const void* table_dev, int n, long total_tiles, int dtype, hipStream_t stream) {
+  UNETDC_REQUIRE(table_dev && n > 0 && total_tiles > 0 && total_tiles < (1L << 31), "pack_many: empty table");
+  UNETDC_REQUIRE(dtype == UNETDC_F32 || dtype == UNETDC_BF16, "pack_many: bad dtype %d", dtype);
+  const PackDesc* t = reinterpret_cast<const PackDesc*>(table_dev);
+  if (dtype == UNETDC_BF16)
+    hipLaunchKernelGGL(pack_many_kernel<bf16_t>, dim3((unsigned)total_tiles), dim3(256), 0, stream, t, n);
+  else
+    hipLaunchKernelGGL(pack_many_kernel<float>, dim3((unsigned)total_tiles), dim3(256), 0, stream, t, n);
+  return check_launch("pack_many_kernel");
 }
 
 }  // namespace unetdc

@@ -162,24 +162,36 @@ class UNetEngine:
         self.x_saved = None
 
     # ------------------------------------------------------------------ weight caches
-    def _pack(self, need_dgrad):
-        s = _stream()
+    def _pack_entries(self):
+        """(parameter, fwd image, dgrad image, a, b, kind) for every packed tensor, in a fixed order."""
+        ent = []
         for st in self.stages.values():
-            if st.first:
-                continue
-            w = st.conv.weight
-            if st.packed_version != w._version or (need_dgrad and not getattr(st, "has_dgrad", False)):
-                call("unetdc_pack_conv3x3", w.data_ptr(), st.w_fwd.data_ptr(),
-                     st.w_dgrad.data_ptr() if need_dgrad else None, st.cout, st.cin, self.dt, s)
-                st.packed_version = w._version
-                st.has_dgrad = need_dgrad
+            if not st.first:
+                ent.append((st.conv.weight, st.w_fwd, st.w_dgrad, st.cout, st.cin, 0))
         for u in self.up.values():
-            w = u["mod"].weight
-            if u["version"] != w._version or (need_dgrad and not u.get("has_dgrad", False)):
-                call("unetdc_pack_convT2x2", w.data_ptr(), u["w_fwd"].data_ptr(),
-                     u["w_dgrad"].data_ptr() if need_dgrad else None, u["cin"], u["cout"], self.dt, s)
-                u["version"] = w._version
-                u["has_dgrad"] = need_dgrad
+            ent.append((u["mod"].weight, u["w_fwd"], u["w_dgrad"], u["cin"], u["cout"], 1))
+        return ent
+
+    def _pack(self, need_dgrad):
+        """Re-pack the K-contiguous compute-type weight images when any parameter changed
+        (optimizer.step(), load_state_dict): ONE launch over a device-resident descriptor table."""
+        import numpy as np
+        ent = self._pack_entries()
+        versions = tuple(w._version for w, *_ in ent)
+        ptrs = tuple(w.data_ptr() for w, *_ in ent)
+        if getattr(self, "_pack_ptrs", None) != ptrs:
+            dt = np.dtype([("w", "<u8"), ("wf", "<u8"), ("wd", "<u8"), ("begin", "<i8"), ("a", "<i4"), ("b", "<i4"),
+                           ("kind", "<i4"), ("pad", "<i4")])
+            tab = np.zeros(len(ent), dtype=dt)
+            off = 0
+            for i, (w, wf, wd, a, b, kind) in enumerate(ent):
+                tab[i] = (w.data_ptr(), wf.data_ptr(), wd.data_ptr(), off, a, b, kind, 0)
+                off += (a // 32) * (b // 32)                 # 32 x 32 channel tiles of this tensor
+            self._pack_table = torch.from_numpy(tab.view(np.uint8).copy()).to(self.device)
+            self._pack_total, self._pack_ptrs, self._pack_versions = off, ptrs, None
+        if self._pack_versions != versions:
+            call("unetdc_pack_many", self._pack_table.data_ptr(), len(ent), self._pack_total, self.dt, _stream())
+            self._pack_versions = versions
 
     # ------------------------------------------------------------------ forward
     def run(self, x):
