@@ -129,13 +129,31 @@ int unetdc_bn_relu_apply(const void* y, int ldy, const float* scale, const float
 /* backward of conv-output y -> BN(train) -> ReLU (-> skip and/or 2x2 max-pool consumers):
  *   incoming gradient = dskip (nullable, full resolution) + scatter(dpool) (nullable, half
  *   resolution, routed to the window arg-max recomputed from y); outputs dy (gradient of the conv
- *   output), dgamma, dbeta and the conv-bias gradient dbias (nullable). */
+ *   output), dgamma, dbeta and the conv-bias gradient dbias (nullable).
+ *   pre_parts (nullable, non-pooled form only): [pre_nparts][3][c] partial sums already produced by
+ *   the *_dgrad_bnstats call that wrote dskip -- the reduction pass over (dskip, y) is then skipped.
+ *   The buffer must have 64 spare rows after pre_nparts. */
 int64_t unetdc_bn_relu_bwd_workspace(int n, int h, int w, int c, int pooled, int dtype);
 int unetdc_bn_relu_bwd(const void* dskip, int ldskip, const void* dpool, int ldpool, const void* y, int ldy,
                        const float* scale, const float* shift, const float* mean, const float* rstd,
                        const float* gamma, void* dy, int lddy, float* dgamma, float* dbeta, float* dbias,
-                       void* workspace, int64_t workspace_bytes, int n, int h, int w, int c, int dtype,
-                       unetdc_stream_t s);
+                       void* workspace, int64_t workspace_bytes, const float* pre_parts, int pre_nparts, int n, int h,
+                       int w, int c, int dtype, unetdc_stream_t s);
+/* dgrad fused with the BatchNorm-backward REDUCTION of the stage that consumes dx: besides dx the
+ * kernel epilogue accumulates, per channel of dx, S1 = sum dx*[n>0] and S2 = sum dx*[n>0]*xhat with
+ * n = scale*y_prev + shift, xhat = (y_prev - mean)*rstd (y_prev = that stage's saved conv output, same
+ * pixel grid as dx).  parts: [*nparts][3][cin] fp32 (third row zero), parts_floats >= (rows+64)*3*cin
+ * with rows = unetdc_conv3x3_stats_rows(n*h*w, cin); *nparts receives the rows written.  The y_prev
+ * read overlaps with matrix-core work here instead of costing a separate HBM pass. */
+int unetdc_conv3x3_dgrad_bnstats(const void* dy, int lddy, const void* w_dgrad, void* dx, int lddx,
+                                 const void* y_prev, int ldy_prev, const float* scale, const float* shift,
+                                 const float* mean, const float* rstd, float* parts, int64_t parts_floats,
+                                 int* nparts, int n, int h, int w, int cin, int cout, int dilation, int dtype,
+                                 unetdc_stream_t s);
+int unetdc_convT2x2_dgrad_bnstats(const void* dup, int lddup, const void* w_dgrad, void* dx, int lddx,
+                                  const void* y_prev, int ldy_prev, const float* scale, const float* shift,
+                                  const float* mean, const float* rstd, float* parts, int64_t parts_floats,
+                                  int* nparts, int n, int h, int w, int cin, int cout, int dtype, unetdc_stream_t s);
 
 /* ---- head: Conv2d(C, OC, 1) + sigmoid, models/model_2.py:32,79-80 ------------------------------
  * w [OC][C] fp32, probs/dprobs NCHW fp32 [n][OC][h][w]. */

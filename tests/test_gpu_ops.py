@@ -250,7 +250,7 @@ def test_bn_relu_fwd_bwd(dtype, pool, case):
     call("unetdc_bn_relu_bwd", dsv.data_ptr(), dsv.stride(0), None if dpv is None else dpv.data_ptr(),
          0 if dpv is None else dpv.stride(0), yv.data_ptr(), yv.stride(0), scale.data_ptr(), shift.data_ptr(),
          mean.data_ptr(), rstd.data_ptr(), gd.data_ptr(), dyv.data_ptr(), dyv.stride(0), dgam.data_ptr(),
-         dbet.data_ptr(), dbias.data_ptr(), ws.data_ptr(), nbytes, n, h, w, c, G.DT[dtype], G.stream())
+         dbet.data_ptr(), dbias.data_ptr(), ws.data_ptr(), nbytes, None, 0, n, h, w, c, G.DT[dtype], G.stream())
     tol = 2e-5 if dtype == "f32" else 2e-2      # bf16: relu/argmax decided on rounded activations
     assert rel(dgam.cpu(), gg_ref) < tol, ("dgamma", rel(dgam.cpu(), gg_ref))
     assert rel(dbet.cpu(), gb_ref) < tol, ("dbeta", rel(dbet.cpu(), gb_ref))
@@ -328,3 +328,62 @@ def test_pack_many_matches_per_layer_packers():
         torch.cuda.synchronize()
         for (w, wf, wd, *_), (of, od) in zip(ent, outs):
             assert torch.equal(of, wf) and torch.equal(od, wd)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 16, 24, 64, 64, 1), (1, 32, 32, 128, 256, 4), (2, 256, 256, 64, 64, 1),
+                                  (1, 512, 256, 128, 64, 2)])
+def test_dgrad_with_fused_bn_backward_statistics(dtype, case):
+    """conv dgrad whose epilogue also emits the BatchNorm-backward partial sums of the consuming stage
+    (S1 = sum dx*[n>0], S2 = sum dx*[n>0]*xhat), and bn_relu_bwd consuming them instead of its own pass."""
+    import ctypes
+    n, h, w, cin, cout, d = case
+    g = gen(19)
+    wt = G.quant(torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5), dtype)
+    dy = G.quant(torch.randn(n, cout, h, w, generator=g), dtype)
+    yprev = G.quant(torch.randn(n, cin, h, w, generator=g) * 1.5 + 0.3, dtype)      # saved conv output of the consumer
+    gamma, beta = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.2
+    xr = torch.zeros(n, cin, h, w, requires_grad=True)
+    dx_ref, = torch.autograd.grad(F.conv2d(xr, wt, None, padding=d, dilation=d), xr, dy)
+    yd = yprev.double()
+    mean, var = yd.mean(dim=(0, 2, 3)), yd.var(dim=(0, 2, 3), unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale, shift = gamma.double() * rstd, beta.double() - mean * gamma.double() * rstd
+    _, wd = G.pack_conv(wt, dtype)
+    dyv, dxv, ypv = G.to_nhwc(dy, dtype), G.empty_nhwc(n * h * w, cin, dtype), G.to_nhwc(yprev, dtype)
+    dev = lambda t_: t_.float().cuda()      # noqa: E731
+    sc, sh, mu, rs = dev(scale), dev(shift), dev(mean), dev(rstd)
+    rows = _lib.load().unetdc_conv3x3_stats_rows(n * h * w, cin)
+    parts = torch.full(((rows + 64) * 3 * cin,), float("nan"), device="cuda")
+    npart = ctypes.c_int(0)
+    call("unetdc_conv3x3_dgrad_bnstats", dyv.data_ptr(), dyv.stride(0), wd.data_ptr(), dxv.data_ptr(), dxv.stride(0),
+         ypv.data_ptr(), ypv.stride(0), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), parts.data_ptr(),
+         parts.numel(), ctypes.byref(npart), n, h, w, cin, cout, d, G.DT[dtype], G.stream())
+    dx = G.from_nhwc(dxv, n, h, w)
+    assert rel(dx, dx_ref) < TOL[dtype]
+    # expected sums from the STORED dx (what bn_relu_bwd would read) -- fp64
+    nrm = yd * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    gh = torch.where(nrm > 0, dx.double(), torch.zeros_like(nrm))
+    xh = (yd - mean.view(1, -1, 1, 1)) * rstd.view(1, -1, 1, 1)
+    pc = parts.cpu()[: npart.value * 3 * cin].reshape(npart.value, 3, cin).double().sum(0)
+    tol = 2e-4 if dtype == "f32" else 2e-2
+    s1, s2 = gh.sum(dim=(0, 2, 3)), (gh * xh).sum(dim=(0, 2, 3))
+    assert float((pc[0] - s1).abs().max()) <= tol * float(gh.abs().sum(dim=(0, 2, 3)).max())
+    assert float((pc[1] - s2).abs().max()) <= tol * float((gh * xh).abs().sum(dim=(0, 2, 3)).max())
+    assert float(pc[2].abs().max()) == 0.0
+    # bn_relu_bwd with the precomputed partial sums == bn_relu_bwd doing its own reduction
+    f32 = dict(device="cuda", dtype=torch.float32)
+    gd = gamma.cuda()
+    outs = []
+    for pre in (None, parts):
+        nbytes = _lib.load().unetdc_bn_relu_bwd_workspace(n, h, w, cin, 0, G.DT[dtype])
+        ws = G.workspace(nbytes)
+        o = G.empty_nhwc(n * h * w, cin, dtype)
+        dgam, dbet, dbias = (torch.full((cin,), float("nan"), **f32) for _ in range(3))
+        call("unetdc_bn_relu_bwd", dxv.data_ptr(), dxv.stride(0), None, 0, ypv.data_ptr(), ypv.stride(0), sc.data_ptr(),
+             sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), gd.data_ptr(), o.data_ptr(), o.stride(0), dgam.data_ptr(),
+             dbet.data_ptr(), dbias.data_ptr(), ws.data_ptr(), nbytes, None if pre is None else pre.data_ptr(),
+             0 if pre is None else npart.value, n, h, w, cin, G.DT[dtype], G.stream())
+        outs.append((o.float().cpu(), dgam.cpu(), dbet.cpu()))
+    assert rel(outs[1][0], outs[0][0]) < (1e-5 if dtype == "f32" else 4e-3)
+    assert rel(outs[1][1], outs[0][1]) < 1e-4 and rel(outs[1][2], outs[0][2]) < 1e-4

@@ -91,6 +91,61 @@ int unetdc_conv3x3_dgrad(const void* dy, int lddy, const void* w_dgrad, void* dx
   return launch_igemm(p, dtype, (hipStream_t)s);
 }
 
+// dgrad whose epilogue also produces the BatchNorm-backward partial sums of the stage that consumes dx
+static int dgrad_bnstats_common(IgemmParams& p, const void* y_prev, int ldy_prev, const float* scale,
+                                const float* shift, const float* mean, const float* rstd, float* parts,
+                                int64_t parts_floats, int* nparts, int n, int h, int w, int c_prev, int dtype,
+                                hipStream_t stream) {
+  UNETDC_REQUIRE(y_prev && scale && shift && mean && rstd && parts && nparts, "dgrad_bnstats: null pointer");
+  const int rows = igemm_mblocks((long)p.M, p.Cout);
+  UNETDC_REQUIRE((int64_t)(rows + 64) * 3 * c_prev <= parts_floats, "dgrad_bnstats: partial buffer too small");
+  p.mode = MODE_BNBWD;
+  p.stats = parts; p.bn_y = y_prev; p.bn_ldy = ldy_prev; p.scale = scale; p.shift = shift; p.bn_mean = mean; p.bn_rstd = rstd;
+  int rc = launch_igemm(p, dtype, stream);
+  if (rc == UNETDC_OK) { *nparts = rows; return rc; }
+  if (rc != UNETDC_EUNSUPPORTED) return rc;
+  // first-generation kernel selected: plain dgrad, then the standalone reduction pass
+  p.mode = MODE_STORE; p.stats = nullptr;
+  rc = launch_igemm(p, dtype, stream);
+  if (rc != UNETDC_OK) return rc;
+  BnBwdParams b{};
+  b.dskip = p.out; b.lds = p.ldo; b.y = y_prev; b.ldy = ldy_prev; b.scale = scale; b.shift = shift; b.mean = mean;
+  b.rstd = rstd; b.N = n; b.H = h; b.W = w; b.C = c_prev;
+  return launch_bn_bwd_reduce_only(b, parts, (long)parts_floats, nparts, dtype, stream);
+}
+
+int unetdc_conv3x3_dgrad_bnstats(const void* dy, int lddy, const void* w_dgrad, void* dx, int lddx,
+                                            const void* y_prev, int ldy_prev, const float* scale, const float* shift,
+                                            const float* mean, const float* rstd, float* parts, int64_t parts_floats,
+                                            int* nparts, int n, int h, int w, int cin, int cout, int dilation,
+                                            int dtype, unetdc_stream_t s) {
+  GEOM_CHECK(n, h, w);
+  UNETDC_REQUIRE(dilation >= 1 && lddy >= cout && lddx >= cin, "conv3x3_dgrad_bnstats: bad dilation/ld");
+  IgemmParams p{};
+  p.x = dy; p.w = w_dgrad; p.out = dx;
+  p.M = n * h * w; p.Ho = h; p.Wo = w; p.Hi = h; p.Wi = w; p.Cin = cout; p.Cout = cin; p.ldx = lddy; p.ldo = lddx;
+  p.ntaps = 9; p.stride = 1;
+  taps3x3(dilation, p.offy, p.offx);
+  return dgrad_bnstats_common(p, y_prev, ldy_prev, scale, shift, mean, rstd, parts, parts_floats, nparts, n, h, w,
+                              cin, dtype, (hipStream_t)s);
+}
+
+int unetdc_convT2x2_dgrad_bnstats(const void* dup, int lddup, const void* w_dgrad, void* dx, int lddx,
+                                             const void* y_prev, int ldy_prev, const float* scale, const float* shift,
+                                             const float* mean, const float* rstd, float* parts,
+                                             int64_t parts_floats, int* nparts, int n, int h, int w, int cin, int cout,
+                                             int dtype, unetdc_stream_t s) {
+  GEOM_CHECK(n, h, w);
+  UNETDC_REQUIRE(lddup >= cout && lddx >= cin, "convT2x2_dgrad_bnstats: ld smaller than channel count");
+  IgemmParams p{};
+  p.x = dup; p.w = w_dgrad; p.out = dx;
+  p.M = n * h * w; p.Ho = h; p.Wo = w; p.Hi = 2 * h; p.Wi = 2 * w; p.Cin = cout; p.Cout = cin; p.ldx = lddup;
+  p.ldo = lddx; p.ntaps = 4; p.stride = 2;
+  for (int t = 0; t < 4; ++t) { p.offy[t] = t >> 1; p.offx[t] = t & 1; }
+  return dgrad_bnstats_common(p, y_prev, ldy_prev, scale, shift, mean, rstd, parts, parts_floats, nparts, n, h, w,
+                              cin, dtype, (hipStream_t)s);
+}
+
 int64_t unetdc_conv3x3_wgrad_workspace(int n, int h, int w, int cin, int cout, int dtype) {
   long b = wgrad_workspace_bytes((long)n * h * w, cout, cin, 9, dtype);
   if (w % 32 == 0 && h >= 8) {          // the tap-fused kernel may be chosen
@@ -208,13 +263,14 @@ int64_t unetdc_bn_relu_bwd_workspace(int n, int h, int w, int c, int pooled, int
 int unetdc_bn_relu_bwd(const void* dskip, int ldskip, const void* dpool, int ldpool, const void* y, int ldy,
                        const float* scale, const float* shift, const float* mean, const float* rstd,
                        const float* gamma, void* dy, int lddy, float* dgamma, float* dbeta, float* dbias,
-                       void* workspace, int64_t workspace_bytes, int n, int h, int w, int c, int dtype,
-                       unetdc_stream_t s) {
+                       void* workspace, int64_t workspace_bytes, const float* pre_parts, int pre_nparts, int n, int h,
+                       int w, int c, int dtype, unetdc_stream_t s) {
   GEOM_CHECK(n, h, w);
   BnBwdParams p{};
   p.dskip = dskip; p.dpool = dpool; p.y = y; p.dy = dy; p.scale = scale; p.shift = shift; p.mean = mean; p.rstd = rstd;
   p.N = n; p.H = h; p.W = w; p.C = c; p.lds = ldskip; p.ldp = ldpool; p.ldy = ldy; p.lddy = lddy;
-  return launch_bn_bwd(p, gamma, dgamma, dbeta, dbias, workspace, (long)workspace_bytes, dtype, (hipStream_t)s);
+  return launch_bn_bwd(p, gamma, dgamma, dbeta, dbias, workspace, (long)workspace_bytes, pre_parts, pre_nparts, dtype,
+                       (hipStream_t)s);
 }
 
 int unetdc_head_fwd(const void* a, int lda, const float* w, const float* b, float* probs, int n, int h, int wd,

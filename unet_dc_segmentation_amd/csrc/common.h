@@ -101,6 +101,19 @@ template <> struct Chunk<bf16_t> {
   }
 };
 
+// two adjacent elements of T as one memory transaction, kept raw so that several can be in flight
+template <typename T> struct PairRaw;
+template <> struct PairRaw<bf16_t> {
+  typedef unsigned int raw_t;
+  __device__ static __forceinline__ raw_t load(const bf16_t* p) { return *reinterpret_cast<const unsigned int*>(p); }
+  __device__ static __forceinline__ void unpack(raw_t r, float& a, float& b) { a = bits_f32(r << 16); b = bits_f32(r & 0xffff0000u); }
+};
+template <> struct PairRaw<float> {
+  typedef float2 raw_t;
+  __device__ static __forceinline__ raw_t load(const float* p) { return *reinterpret_cast<const float2*>(p); }
+  __device__ static __forceinline__ void unpack(raw_t r, float& a, float& b) { a = r.x; b = r.y; }
+};
+
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
 

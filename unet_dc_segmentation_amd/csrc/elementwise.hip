@@ -613,8 +613,28 @@ static void launch_bn_bwd_k(const BnBwdParams& p, bool pool, bool apply, dim3 gr
   }
 }
 
+// Reduction pass only: fills `parts` ([nparts][3][C]) -- used when the producer kernel could not fuse it.
+int launch_bn_bwd_reduce_only(BnBwdParams& p, float* parts, long parts_floats, int* nparts, int dtype,
+                              hipStream_t stream) {
+  const int epc = dtype == UNETDC_BF16 ? 8 : 4;
+  UNETDC_REQUIRE(p.y && p.dskip && parts && nparts, "bn_bwd_reduce: null pointer");
+  const int cpp = p.C / epc;
+  const int seg = cpp < 256 ? cpp : 256;
+  UNETDC_REQUIRE(p.C % epc == 0 && 256 % seg == 0, "bn_bwd_reduce: C=%d unsupported", p.C);
+  const long Q = (long)p.N * p.H * p.W;
+  const int nb = bn_bwd_blocks(Q, cpp);
+  UNETDC_REQUIRE((long)(nb + 64) * 3 * p.C <= parts_floats, "bn_bwd_reduce: partial buffer too small");
+  p.parts = parts;
+  p.dpool = nullptr;
+  const dim3 grid(nb, (cpp + seg - 1) / seg);
+  if (dtype == UNETDC_BF16) launch_bn_bwd_k<bf16_t>(p, false, false, grid, stream);
+  else launch_bn_bwd_k<float>(p, false, false, grid, stream);
+  *nparts = nb;
+  return check_launch("bn_bwd_kernel(reduce)");
+}
+
 int launch_bn_bwd(BnBwdParams& p, const float* gamma, float* dgamma, float* dbeta, float* dbias, void* workspace,
-                  long workspace_bytes, int dtype, hipStream_t stream) {
+                  long workspace_bytes, const float* pre_parts, int pre_nparts, int dtype, hipStream_t stream) {
   const int epc = dtype == UNETDC_BF16 ? 8 : 4;
   UNETDC_REQUIRE(dtype == UNETDC_F32 || dtype == UNETDC_BF16, "bn_bwd: bad dtype %d", dtype);
   UNETDC_REQUIRE(p.y && p.dy && (p.dskip || p.dpool), "bn_bwd: null tensor");
@@ -624,6 +644,7 @@ int launch_bn_bwd(BnBwdParams& p, const float* gamma, float* dgamma, float* dbet
   if (pool) UNETDC_REQUIRE(p.H % 2 == 0 && p.W % 2 == 0 && p.ldp % epc == 0, "bn_bwd: pooling needs even H, W");
   if (!pool) UNETDC_REQUIRE(p.dskip != nullptr, "bn_bwd: gradient missing");
   if (p.dskip) UNETDC_REQUIRE(p.lds % epc == 0, "bn_bwd: lds not chunk aligned");
+  if (pre_parts) UNETDC_REQUIRE(!pool && pre_nparts > 0, "bn_bwd: precomputed partial sums need the non-pooled form");
   const int cpp = p.C / epc;
   const int seg = cpp < 256 ? cpp : 256;
   UNETDC_REQUIRE(256 % seg == 0, "bn_bwd: C=%d unsupported (C/%d must divide 256 or be a multiple of 256)", p.C, epc);
@@ -640,12 +661,18 @@ int launch_bn_bwd(BnBwdParams& p, const float* gamma, float* dgamma, float* dbet
   p.parts = parts;
   p.k1 = k; p.k2 = k + p.C; p.k3 = k + 2 * p.C;
   const dim3 grid(nb, (cpp + seg - 1) / seg);
-  if (dtype == UNETDC_BF16) launch_bn_bwd_k<bf16_t>(p, pool, false, grid, stream);
-  else launch_bn_bwd_k<float>(p, pool, false, grid, stream);
-  int rc = check_launch("bn_bwd_kernel(reduce)");
-  if (rc != UNETDC_OK) return rc;
+  int rc;
   const float* rp; int rows;
-  rc = reduce_parts(parts, nb, 3 * p.C, &rp, &rows, stream);
+  if (pre_parts) {
+    // the reduction was fused into the epilogue of the kernel that produced the gradient
+    rc = reduce_parts(pre_parts, pre_nparts, 3 * p.C, &rp, &rows, stream);
+  } else {
+    if (dtype == UNETDC_BF16) launch_bn_bwd_k<bf16_t>(p, pool, false, grid, stream);
+    else launch_bn_bwd_k<float>(p, pool, false, grid, stream);
+    rc = check_launch("bn_bwd_kernel(reduce)");
+    if (rc != UNETDC_OK) return rc;
+    rc = reduce_parts(parts, nb, 3 * p.C, &rp, &rows, stream);
+  }
   if (rc != UNETDC_OK) return rc;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 7) / 8), dim3(256), 0, stream, rp, rows,
                      (double)p.N * p.H * p.W, gamma, p.rstd, dgamma, dbeta, dbias, k, k + p.C, k + 2 * p.C, p.C);

@@ -335,8 +335,11 @@ int launch_igemm(IgemmParams& p, int dtype, hipStream_t stream) {
   if (p.mode == MODE_SHUFFLE) UNETDC_REQUIRE(p.shuf_c % 64 == 0, "igemm: convT channels must be a multiple of 64");
   if (p.mode == MODE_STATS) UNETDC_REQUIRE(p.stats != nullptr, "igemm: stats buffer missing");
   if (p.mode == MODE_AFFINE_RELU) UNETDC_REQUIRE(p.scale && p.shift, "igemm: scale/shift missing");
+  if (p.mode == MODE_BNBWD)
+    UNETDC_REQUIRE(p.stats && p.bn_y && p.scale && p.shift && p.bn_mean && p.bn_rstd, "igemm: BN-backward inputs missing");
   if (igemm_choice() == 0 && igemm_halo_supported(p, dtype)) return launch_igemm_halo(p, dtype, stream);
   if (!use_legacy() && igemm_dma_supported(p, dtype)) return launch_igemm_dma(p, dtype, stream);
+  if (p.mode == MODE_BNBWD) return UNETDC_EUNSUPPORTED;      // first-generation kernel: caller reduces separately
   const bool wide = (p.Cout % 128 == 0) && p.mode != MODE_STATS;     // statistics rows assume BM = 256
   if (dtype == UNETDC_BF16)
     return wide ? launch_cfg<bf16_t, 2, 2>(p, stream) : launch_cfg<bf16_t, 4, 1>(p, stream);

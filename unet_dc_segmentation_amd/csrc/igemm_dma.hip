@@ -201,9 +201,18 @@ __global__ __launch_bounds__(512, 2) void igemm_dma_kernel(const IgemmParams p) 
     shuf_ab = col / p.shuf_c;
     shuf_co = col - shuf_ab * p.shuf_c;
     if (p.bias) { k1a = p.bias[shuf_co]; k1b = p.bias[shuf_co + 1]; }
+  } else if (p.mode == MODE_BNBWD) {
+    k0a = p.scale[col]; k0b = p.scale[col + 1];
+    k1a = p.shift[col]; k1b = p.shift[col + 1];
   } else if (p.bias) {
     k1a = p.bias[col]; k1b = p.bias[col + 1];
   }
+  float mua = 0.f, mub = 0.f, rsa = 0.f, rsb = 0.f;
+  if (p.mode == MODE_BNBWD) {
+    mua = p.bn_mean[col]; mub = p.bn_mean[col + 1];
+    rsa = p.bn_rstd[col]; rsb = p.bn_rstd[col + 1];
+  }
+  const T* __restrict__ yg = reinterpret_cast<const T*>(p.bn_y);
   float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
   const bool fastrow = (p.Wo & 31) == 0;        // a 32-row MFMA tile then lies inside one image row
 #pragma unroll
@@ -215,6 +224,15 @@ __global__ __launch_bounds__(512, 2) void igemm_dma_kernel(const IgemmParams p) 
       const int rem = mb - bn * HoWo;
       boy = rem / p.Wo;
       box = rem - boy * p.Wo;
+    }
+    // BN-backward fusion: fetch this tile's 16 (y, y+1) pairs up front so the loads overlap each other
+    typename PairRaw<T>::raw_t yraw[16];
+    if (p.mode == MODE_BNBWD) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int m = mb + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        yraw[reg] = PairRaw<T>::load(yg + (long)(m < p.M ? m : 0) * p.bn_ldy + col);
+      }
     }
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
@@ -237,6 +255,14 @@ __global__ __launch_bounds__(512, 2) void igemm_dma_kernel(const IgemmParams p) 
         }
         const long dst = ((long)(n * 2 * p.Ho + 2 * oy + (shuf_ab >> 1)) * (2 * p.Wo) + 2 * ox + (shuf_ab & 1));
         store_pair_d<T>(og + dst * p.ldo + shuf_co, v0, v1);
+      } else if (p.mode == MODE_BNBWD) {
+        store_pair_d<T>(og + (long)m * p.ldo + col, v0, v1);
+        float y0, y1;
+        PairRaw<T>::unpack(yraw[reg], y0, y1);
+        const float g0 = fmaf(y0, k0a, k1a) > 0.f ? round_through<T>(v0) : 0.f;
+        const float g1 = fmaf(y1, k0b, k1b) > 0.f ? round_through<T>(v1) : 0.f;
+        s0 += g0; q0 = fmaf(g0, (y0 - mua) * rsa, q0);
+        s1 += g1; q1 = fmaf(g1, (y1 - mub) * rsb, q1);
       } else {
         v0 += k1a; v1 += k1b;
         store_pair_d<T>(og + (long)m * p.ldo + col, v0, v1);
@@ -248,7 +274,8 @@ __global__ __launch_bounds__(512, 2) void igemm_dma_kernel(const IgemmParams p) 
       }
     }
   }
-  if (p.mode == MODE_STATS) {
+  if (p.mode == MODE_STATS || p.mode == MODE_BNBWD) {
+    const int nrow = (p.mode == MODE_BNBWD) ? 3 : 2;          // BN-backward partials carry a third (zero) row
     s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
     s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
     __syncthreads();                                         // all waves are done with the stage buffers
@@ -268,8 +295,9 @@ __global__ __launch_bounds__(512, 2) void igemm_dma_kernel(const IgemmParams p) 
         su += red[((w2 * WN + wn2) * 4 + e * 2 + 0) * 32 + r2];
         sq += red[((w2 * WN + wn2) * 4 + e * 2 + 1) * 32 + r2];
       }
-      p.stats[((long)mblk * 2 + 0) * p.Cout + n0 + tid] = su;
-      p.stats[((long)mblk * 2 + 1) * p.Cout + n0 + tid] = sq;
+      p.stats[((long)mblk * nrow + 0) * p.Cout + n0 + tid] = su;
+      p.stats[((long)mblk * nrow + 1) * p.Cout + n0 + tid] = sq;
+      if (nrow == 3) p.stats[((long)mblk * 3 + 2) * p.Cout + n0 + tid] = 0.f;
     }
   }
 #endif  // __HIP_DEVICE_COMPILE__

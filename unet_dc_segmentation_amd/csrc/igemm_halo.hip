@@ -190,13 +190,28 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(const IgemmParams p,
   if (p.mode == MODE_AFFINE_RELU) {
     k0a = p.scale[col]; k0b = p.scale[col + 1];
     k1a = p.shift[col]; k1b = p.shift[col + 1];
+  } else if (p.mode == MODE_BNBWD) {
+    k0a = p.scale[col]; k0b = p.scale[col + 1];
+    k1a = p.shift[col]; k1b = p.shift[col + 1];
   } else if (p.bias) {
     k1a = p.bias[col]; k1b = p.bias[col + 1];
   }
+  float mua = 0.f, mub = 0.f, rsa = 0.f, rsb = 0.f;
+  if (p.mode == MODE_BNBWD) {
+    mua = p.bn_mean[col]; mub = p.bn_mean[col + 1];
+    rsa = p.bn_rstd[col]; rsb = p.bn_rstd[col + 1];
+  }
+  const T* __restrict__ yg = reinterpret_cast<const T*>(p.bn_y);
   float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
     const long rowpix = ((long)img * p.Ho + y0 + wm * 2 + mi) * p.Wo + x0;
+    typename PairRaw<T>::raw_t yraw[16];
+    if (p.mode == MODE_BNBWD) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg)
+        yraw[reg] = PairRaw<T>::load(yg + (rowpix + (reg & 3) + 8 * (reg >> 2) + 4 * h) * p.bn_ldy + col);
+    }
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int tx = (reg & 3) + 8 * (reg >> 2) + 4 * h;
@@ -206,6 +221,14 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(const IgemmParams p,
         v0 = fmaxf(fmaf(v0, k0a, k1a), 0.f);
         v1 = fmaxf(fmaf(v1, k0b, k1b), 0.f);
         store_pair_h<T>(dst, v0, v1);
+      } else if (p.mode == MODE_BNBWD) {
+        store_pair_h<T>(dst, v0, v1);
+        float y0, y1;
+        PairRaw<T>::unpack(yraw[reg], y0, y1);
+        const float g0 = fmaf(y0, k0a, k1a) > 0.f ? round_through<T>(v0) : 0.f;
+        const float g1 = fmaf(y1, k0b, k1b) > 0.f ? round_through<T>(v1) : 0.f;
+        s0 += g0; q0 = fmaf(g0, (y0 - mua) * rsa, q0);
+        s1 += g1; q1 = fmaf(g1, (y1 - mub) * rsb, q1);
       } else {
         v0 += k1a; v1 += k1b;
         store_pair_h<T>(dst, v0, v1);
@@ -217,7 +240,8 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(const IgemmParams p,
       }
     }
   }
-  if (p.mode == MODE_STATS) {
+  if (p.mode == MODE_STATS || p.mode == MODE_BNBWD) {
+    const int nrow = (p.mode == MODE_BNBWD) ? 3 : 2;
     s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
     s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
     __syncthreads();
@@ -237,8 +261,9 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(const IgemmParams p,
         su += red[((w2 * WN + wn2) * 4 + e * 2 + 0) * 32 + r2];
         sq += red[((w2 * WN + wn2) * 4 + e * 2 + 1) * 32 + r2];
       }
-      p.stats[((long)mtile * 2 + 0) * p.Cout + n0 + tid] = su;
-      p.stats[((long)mtile * 2 + 1) * p.Cout + n0 + tid] = sq;
+      p.stats[((long)mtile * nrow + 0) * p.Cout + n0 + tid] = su;
+      p.stats[((long)mtile * nrow + 1) * p.Cout + n0 + tid] = sq;
+      if (nrow == 3) p.stats[((long)mtile * 3 + 2) * p.Cout + n0 + tid] = 0.f;
     }
   }
 #endif  // __HIP_DEVICE_COMPILE__

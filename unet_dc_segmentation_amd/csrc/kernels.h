@@ -4,7 +4,11 @@
 
 namespace unetdc {
 
-enum { MODE_STORE = 0, MODE_STATS = 1, MODE_AFFINE_RELU = 2, MODE_SHUFFLE = 3 };
+// MODE_BNBWD: plain store of a gradient tensor dA plus, fused, the per-channel partial sums of the
+// BatchNorm-backward reduction of the stage that consumes dA:  S1 = sum dA*[n>0], S2 = sum dA*[n>0]*xhat
+// with n = scale*y + shift, xhat = (y - mean)*rstd read from that stage's saved conv output y.
+enum { MODE_STORE = 0, MODE_STATS = 1, MODE_AFFINE_RELU = 2, MODE_SHUFFLE = 3, MODE_BNBWD = 4 };
+#define UNETDC_EUNSUPPORTED (-4)
 
 struct IgemmParams {
   const void* x;
@@ -14,6 +18,10 @@ struct IgemmParams {
   const float* scale;
   const float* shift;
   float* stats;
+  const void* bn_y;          // MODE_BNBWD: saved conv output of the consuming stage, [M][bn_ldy]
+  const float* bn_mean;
+  const float* bn_rstd;
+  int bn_ldy;
   int M, Ho, Wo, Hi, Wi, Cin, Cout, ldx, ldo, ntaps, stride, mode, shuf_c;
   int mblocks, nblocks;
   int offy[9];
@@ -85,7 +93,9 @@ int launch_bn_eval_affine(const float* gamma, const float* beta, const float* rm
 int launch_apply(ApplyParams& p, int dtype, hipStream_t stream);
 long bn_bwd_workspace_bytes(int N, int H, int W, int C, int pooled, int dtype);
 int launch_bn_bwd(BnBwdParams& p, const float* gamma, float* dgamma, float* dbeta, float* dbias, void* workspace,
-                  long workspace_bytes, int dtype, hipStream_t stream);
+                  long workspace_bytes, const float* pre_parts, int pre_nparts, int dtype, hipStream_t stream);
+int launch_bn_bwd_reduce_only(BnBwdParams& p, float* parts, long parts_floats, int* nparts, int dtype,
+                              hipStream_t stream);
 long head_bwd_workspace_bytes(int N, int H, int W, int C, int OC, int dtype);
 int launch_head_fwd(HeadParams& p, int dtype, hipStream_t stream);
 int launch_head_bwd(HeadParams& p, float* dw, float* db, void* workspace, long workspace_bytes, int dtype,

@@ -25,7 +25,11 @@ import torch
 from . import _lib
 from ._lib import call
 
+import os
+
 ENCODER = ("enc1", "enc2", "enc3", "enc4")
+# fuse the BatchNorm-backward reduction into the dgrad epilogue that produces the gradient (A/B switch)
+FUSE_BN_BWD = os.environ.get("UNETDC_FUSE_BNBWD", "1") != "0"
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
@@ -62,6 +66,11 @@ class _Stage:
         self.packed_version = -1
         self.x_in = None      # input view of the last forward (for wgrad)
         self.a_out = None     # activated output view
+        # BatchNorm-backward partial sums produced by the dgrad kernel that writes this stage's
+        # incoming gradient (fused reduction); rows = 256-pixel blocks, 64 spare rows for the 2nd stage
+        self.bwd_rows = _lib.load().unetdc_conv3x3_stats_rows(npix, cout)
+        self.bwd_parts = None
+        self.bwd_nparts = 0
 
 
 class UNetEngine:
@@ -311,21 +320,34 @@ class UNetEngine:
         i = self.pindex[id(p)]
         return flat[self.poffs[i]: self.poffs[i] + p.numel()]
 
-    def _stage_bwd(self, st, flat, lvl, dskip, dpool, dx_out):
+    def _bnstats_args(self, prev):
+        """Arguments describing the stage whose BN-backward reduction a dgrad epilogue should fuse."""
+        if prev.bwd_parts is None:
+            prev.bwd_parts = torch.empty((prev.bwd_rows + 64) * 3 * prev.cout, device=self.device, dtype=torch.float32)
+        self._np = getattr(self, "_np", None) or __import__("ctypes").c_int(0)
+        return (prev.y.data_ptr(), prev.y.stride(0), prev.scale.data_ptr(), prev.shift.data_ptr(),
+                prev.mean.data_ptr(), prev.rstd.data_ptr(), prev.bwd_parts.data_ptr(), prev.bwd_parts.numel(),
+                __import__("ctypes").byref(self._np))
+
+    def _stage_bwd(self, st, flat, lvl, dskip, dpool, dx_out, fuse_prev=None):
         """Backward of one stage.  dskip/dpool: incoming gradient(s) of the activation;
-        dx_out: [npix, cin] view to receive the input gradient (None for the first stage)."""
+        dx_out: [npix, cin] view to receive the input gradient (None for the first stage);
+        fuse_prev: the stage consuming dx_out as its activation gradient -- its BatchNorm-backward
+        reduction is then fused into this stage's dgrad epilogue."""
         s = _stream()
         N = self.N
         h, w = st.hw
         g = self.grad_bufs
         dy = g[("dy", lvl)]
         ws, wsb = self.workspace.data_ptr(), self.ws_bytes
+        pre = (st.bwd_parts.data_ptr(), st.bwd_nparts) if (st.bwd_nparts and dpool is None) else (None, 0)
         call("unetdc_bn_relu_bwd", _ptr(dskip), dskip.stride(0) if dskip is not None else 0,
              _ptr(dpool), dpool.stride(0) if dpool is not None else 0, st.y.data_ptr(), st.y.stride(0),
              st.scale.data_ptr(), st.shift.data_ptr(), st.mean.data_ptr(), st.rstd.data_ptr(),
              st.bn.weight.data_ptr(), dy.data_ptr(), dy.stride(0), self._gview(flat, st.bn.weight).data_ptr(),
              self._gview(flat, st.bn.bias).data_ptr(), self._gview(flat, st.conv.bias).data_ptr(), ws, wsb,
-             N, h, w, st.cout, self.dt, s)
+             pre[0], pre[1], N, h, w, st.cout, self.dt, s)
+        st.bwd_nparts = 0
         dw = self._gview(flat, st.conv.weight)
         xin = st.x_in
         if st.first:
@@ -334,14 +356,19 @@ class UNetEngine:
         else:
             call("unetdc_conv3x3_wgrad", xin.data_ptr(), xin.stride(0), dy.data_ptr(), dy.stride(0), dw.data_ptr(),
                  ws, wsb, N, h, w, st.cin, st.cout, st.dil, self.dt, s)
-            if dx_out is not None:
+            if dx_out is not None and fuse_prev is not None and FUSE_BN_BWD:
+                call("unetdc_conv3x3_dgrad_bnstats", dy.data_ptr(), dy.stride(0), st.w_dgrad.data_ptr(),
+                     dx_out.data_ptr(), dx_out.stride(0), *self._bnstats_args(fuse_prev), N, h, w, st.cin, st.cout,
+                     st.dil, self.dt, s)
+                fuse_prev.bwd_nparts = self._np.value
+            elif dx_out is not None:
                 call("unetdc_conv3x3_dgrad", dy.data_ptr(), dy.stride(0), st.w_dgrad.data_ptr(), dx_out.data_ptr(),
                      dx_out.stride(0), N, h, w, st.cin, st.cout, st.dil, self.dt, s)
 
     def _block_bwd(self, name, flat, lvl, dskip, dpool, dx_out):
         """stage 3 then stage 0 of a block; the gradient between them lives in the 'da' buffer."""
         da = self.grad_bufs[("da", lvl)]
-        self._stage_bwd(self.stages[(name, 3)], flat, lvl, dskip, dpool, da)
+        self._stage_bwd(self.stages[(name, 3)], flat, lvl, dskip, dpool, da, fuse_prev=self.stages[(name, 0)])
         self._stage_bwd(self.stages[(name, 0)], flat, lvl, da, None, dx_out)
         self._notify(flat, name)
 
@@ -386,8 +413,14 @@ class UNetEngine:
             call("unetdc_channel_sum", dup.data_ptr(), dup.stride(0), self._gview(flat, u["mod"].bias).data_ptr(),
                  ws, wsb, self.npix[l], c, self.dt, s)
             dnext = g[("da", lvl)]               # gradient w.r.t. the up-conv input (level lvl+1 resolution)
-            call("unetdc_convT2x2_dgrad", dup.data_ptr(), dup.stride(0), u["w_dgrad"].data_ptr(), dnext.data_ptr(),
-                 dnext.stride(0), N, h, w, u["cin"], c, self.dt, s)
+            prev = self.stages[("bottleneck" if lvl == 4 else f"dec{lvl + 1}", 3)]     # producer of the up-conv input
+            if FUSE_BN_BWD:
+                call("unetdc_convT2x2_dgrad_bnstats", dup.data_ptr(), dup.stride(0), u["w_dgrad"].data_ptr(),
+                     dnext.data_ptr(), dnext.stride(0), *self._bnstats_args(prev), N, h, w, u["cin"], c, self.dt, s)
+                prev.bwd_nparts = self._np.value
+            else:
+                call("unetdc_convT2x2_dgrad", dup.data_ptr(), dup.stride(0), u["w_dgrad"].data_ptr(),
+                     dnext.data_ptr(), dnext.stride(0), N, h, w, u["cin"], c, self.dt, s)
             self._notify(flat, f"upconv{lvl}")
             dact = dnext
         # bottleneck: input is pool[4]
