@@ -66,6 +66,13 @@ def igemm_flops(name, a, es=2):
     if name == "unetdc_convT2x2_dgrad":
         n, h, w, cin, cout = a[5:10]
         return 2.0 * n * h * w * cin * 4 * cout, (n * h * w * (cin + 4 * cout) + 4 * cin * cout) * es
+    # dgrad fused with the BatchNorm-backward reduction: also reads the consumer's saved conv output once
+    if name == "unetdc_conv3x3_dgrad_bnstats":
+        n, h, w, cin, cout = a[14:19]
+        return 2.0 * n * h * w * cout * cin * 9, (n * h * w * (2 * cin + cout) + 9 * cin * cout) * es
+    if name == "unetdc_convT2x2_dgrad_bnstats":
+        n, h, w, cin, cout = a[14:19]
+        return 2.0 * n * h * w * cin * 4 * cout, (n * h * w * (2 * cin + 4 * cout) + 4 * cin * cout) * es
     raise KeyError(name)
 
 
@@ -117,7 +124,8 @@ def per_layer_table(step, args):
         name = tagged.split("|")[0]
         fl, shape = 0.0, ""
         ints = [v for v in a if isinstance(v, int) and 0 < v < 100000]
-        if name in ("unetdc_conv3x3_fwd", "unetdc_conv3x3_dgrad", "unetdc_convT2x2_fwd", "unetdc_convT2x2_dgrad"):
+        if name in ("unetdc_conv3x3_fwd", "unetdc_conv3x3_dgrad", "unetdc_convT2x2_fwd", "unetdc_convT2x2_dgrad",
+                    "unetdc_conv3x3_dgrad_bnstats", "unetdc_convT2x2_dgrad_bnstats"):
             fl, _ = igemm_flops(name, a)
         elif name == "unetdc_conv3x3_wgrad":
             n, h, w, cin, cout = a[7:12]
@@ -214,7 +222,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    igemm_calls = ["unetdc_conv3x3_fwd", "unetdc_conv3x3_dgrad", "unetdc_convT2x2_fwd", "unetdc_convT2x2_dgrad"]
+    igemm_calls = ["unetdc_conv3x3_fwd", "unetdc_conv3x3_dgrad", "unetdc_convT2x2_fwd", "unetdc_convT2x2_dgrad",
+                   "unetdc_conv3x3_dgrad_bnstats", "unetdc_convT2x2_dgrad_bnstats"]
     if args.per_layer:
         per_layer_table(step, args)
     if world > 1:

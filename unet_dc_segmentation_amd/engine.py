@@ -30,6 +30,8 @@ import os
 ENCODER = ("enc1", "enc2", "enc3", "enc4")
 # fuse the BatchNorm-backward reduction into the dgrad epilogue that produces the gradient (A/B switch)
 FUSE_BN_BWD = os.environ.get("UNETDC_FUSE_BNBWD", "1") != "0"
+# run the weight-gradient kernels (off the backward critical chain) on a side HIP stream (A/B switch)
+SIDE_WGRAD = os.environ.get("UNETDC_SIDE_WGRAD", "1") != "0"
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
@@ -71,6 +73,8 @@ class _Stage:
         self.bwd_rows = _lib.load().unetdc_conv3x3_stats_rows(npix, cout)
         self.bwd_parts = None
         self.bwd_nparts = 0
+        self.dy = None        # gradient of this stage's conv output (own buffer: read by dgrad on the main
+        #                       stream and by wgrad on the side stream)
 
 
 class UNetEngine:
@@ -308,13 +312,36 @@ class UNetEngine:
         widths = [64, 128, 256, 512, 1024]
         for l in range(5):
             c = widths[l]
-            g[("dy", l)] = torch.empty(self.npix[l], c, device=dev, dtype=dt)       # grad of a conv output
             g[("da", l)] = torch.empty(self.npix[l], c, device=dev, dtype=dt)       # grad of an activation
             if l < 4:
                 g[("dcat", l + 1)] = torch.empty(self.npix[l], 2 * c, device=dev, dtype=dt)
                 g[("dpool", l + 1)] = torch.empty(self.npix[l + 1], c, device=dev, dtype=dt)
+        for st in self.stages.values():
+            st.dy = torch.empty(st.npix, st.cout, device=dev, dtype=dt)
         self.grad_bufs = g
         self.workspace = torch.empty(self.ws_bytes, device=dev, dtype=torch.uint8)
+        self.side = torch.cuda.Stream(device=dev) if SIDE_WGRAD else None
+        self.ws_side = torch.empty(self.ws_bytes, device=dev, dtype=torch.uint8) if SIDE_WGRAD else self.workspace
+
+    def _side_after_main(self):
+        """Context: (stream handle, workspace pointer) for work that may leave the critical chain.
+        The side stream first waits for everything enqueued on the main stream so far."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            if self.side is None:
+                yield _stream(), self.workspace.data_ptr()
+                return
+            ev = torch.cuda.Event()
+            ev.record()                                   # main (current) stream
+            self.side.wait_event(ev)
+            yield self.side.cuda_stream, self.ws_side.data_ptr()
+        return ctx()
+
+    def _join_side(self):
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
 
     def _gview(self, flat, p):
         i = self.pindex[id(p)]
@@ -337,8 +364,7 @@ class UNetEngine:
         s = _stream()
         N = self.N
         h, w = st.hw
-        g = self.grad_bufs
-        dy = g[("dy", lvl)]
+        dy = st.dy
         ws, wsb = self.workspace.data_ptr(), self.ws_bytes
         pre = (st.bwd_parts.data_ptr(), st.bwd_nparts) if (st.bwd_nparts and dpool is None) else (None, 0)
         call("unetdc_bn_relu_bwd", _ptr(dskip), dskip.stride(0) if dskip is not None else 0,
@@ -350,12 +376,14 @@ class UNetEngine:
         st.bwd_nparts = 0
         dw = self._gview(flat, st.conv.weight)
         xin = st.x_in
-        if st.first:
-            call("unetdc_conv3x3_first_wgrad", xin.data_ptr(), dy.data_ptr(), dy.stride(0), dw.data_ptr(), ws, wsb,
-                 N, h, w, st.cin, st.cout, st.dil, self.dt, s)
-        else:
-            call("unetdc_conv3x3_wgrad", xin.data_ptr(), xin.stride(0), dy.data_ptr(), dy.stride(0), dw.data_ptr(),
-                 ws, wsb, N, h, w, st.cin, st.cout, st.dil, self.dt, s)
+        with self._side_after_main() as (s2, ws2):
+            if st.first:
+                call("unetdc_conv3x3_first_wgrad", xin.data_ptr(), dy.data_ptr(), dy.stride(0), dw.data_ptr(), ws2, wsb,
+                     N, h, w, st.cin, st.cout, st.dil, self.dt, s2)
+            else:
+                call("unetdc_conv3x3_wgrad", xin.data_ptr(), xin.stride(0), dy.data_ptr(), dy.stride(0), dw.data_ptr(),
+                     ws2, wsb, N, h, w, st.cin, st.cout, st.dil, self.dt, s2)
+        if not st.first:
             if dx_out is not None and fuse_prev is not None and FUSE_BN_BWD:
                 call("unetdc_conv3x3_dgrad_bnstats", dy.data_ptr(), dy.stride(0), st.w_dgrad.data_ptr(),
                      dx_out.data_ptr(), dx_out.stride(0), *self._bnstats_args(fuse_prev), N, h, w, st.cin, st.cout,
@@ -375,6 +403,7 @@ class UNetEngine:
     def _notify(self, flat, name):
         hook = self.model.grad_ready_hook
         if hook is not None:
+            self._join_side()                            # the block's wgrads run on the side stream
             mod = getattr(self.model, name)
             ps = list(mod.parameters())
             lo = self.poffs[self.pindex[id(ps[0])]]
@@ -408,10 +437,11 @@ class UNetEngine:
             dup = dcat[:, :c]
             h, w = self.res[lvl]
             xin = u["x_in"]
-            call("unetdc_convT2x2_wgrad", xin.data_ptr(), xin.stride(0), dup.data_ptr(), dup.stride(0),
-                 self._gview(flat, u["mod"].weight).data_ptr(), ws, wsb, N, h, w, u["cin"], c, self.dt, s)
-            call("unetdc_channel_sum", dup.data_ptr(), dup.stride(0), self._gview(flat, u["mod"].bias).data_ptr(),
-                 ws, wsb, self.npix[l], c, self.dt, s)
+            with self._side_after_main() as (s2, ws2):
+                call("unetdc_convT2x2_wgrad", xin.data_ptr(), xin.stride(0), dup.data_ptr(), dup.stride(0),
+                     self._gview(flat, u["mod"].weight).data_ptr(), ws2, wsb, N, h, w, u["cin"], c, self.dt, s2)
+                call("unetdc_channel_sum", dup.data_ptr(), dup.stride(0), self._gview(flat, u["mod"].bias).data_ptr(),
+                     ws2, wsb, self.npix[l], c, self.dt, s2)
             dnext = g[("da", lvl)]               # gradient w.r.t. the up-conv input (level lvl+1 resolution)
             prev = self.stages[("bottleneck" if lvl == 4 else f"dec{lvl + 1}", 3)]     # producer of the up-conv input
             if FUSE_BN_BWD:
@@ -433,6 +463,9 @@ class UNetEngine:
             dskip = g[("dcat", lvl)][:, c:]
             dx_out = g[("dpool", lvl - 1)] if lvl > 1 else None
             self._block_bwd(name, flat, l, dskip, g[("dpool", lvl)], dx_out)
+        if self.side is not None:
+            flat.record_stream(self.side)
+        self._join_side()
         return flat
 
 
