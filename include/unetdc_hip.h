@@ -164,6 +164,19 @@ int unetdc_head_bwd(const float* dprobs, const float* probs, const void* a, int 
                     int ldda, float* dw, float* db, void* workspace, int64_t workspace_bytes, int n, int h, int wd,
                     int c, int oc, int dtype, unetdc_stream_t s);
 
+/* ---- fused Focal + Dice loss on probabilities: utils/metrics_DC.py:65-73 (FocalLoss :43-63, dice_loss :11-17) ---
+ * probs/target: fp32 [nimg][hw] (nimg = N*C maps, hw pixels each).  fwd writes the scalar loss and the
+ * per-map coefficients {2/(U+s), (2I+s)/(U+s)^2} that bwd needs; bwd writes
+ * dprobs = grad_out[0] * d loss / d probs.  alpha/gamma: focal parameters; ratio: focal weight;
+ * smooth: the Dice smoothing constant (1e-7 in the reference). */
+int64_t unetdc_focal_dice_loss_workspace(int nimg, int64_t hw);
+int unetdc_focal_dice_loss_fwd(const float* probs, const float* target, float* loss_out, float* coef, void* workspace,
+                               int64_t workspace_bytes, int nimg, int64_t hw, float alpha, float gamma, float ratio,
+                               float smooth, unetdc_stream_t s);
+int unetdc_focal_dice_loss_bwd(const float* probs, const float* target, const float* coef, const float* grad_out,
+                               float* dprobs, int nimg, int64_t hw, float alpha, float gamma, float ratio,
+                               unetdc_stream_t s);
+
 /* ---- per-channel column sum of an NHWC tensor (ConvTranspose2d bias gradient) ------------------ */
 int64_t unetdc_channel_sum_workspace(int64_t npixels, int c);
 int unetdc_channel_sum(const void* x, int ldx, float* out, void* workspace, int64_t workspace_bytes,

@@ -387,3 +387,32 @@ def test_dgrad_with_fused_bn_backward_statistics(dtype, case):
         outs.append((o.float().cpu(), dgam.cpu(), dbet.cpu()))
     assert rel(outs[1][0], outs[0][0]) < (1e-5 if dtype == "f32" else 4e-3)
     assert rel(outs[1][1], outs[0][1]) < 1e-4 and rel(outs[1][2], outs[0][2]) < 1e-4
+
+
+@pytest.mark.parametrize("gamma", [2.0, 1.5])
+def test_fused_focal_dice_loss(gamma):
+    """Fused HIP loss vs the reference's own numbers (golden) and vs the PyTorch formulation."""
+    from tests.helpers import load_golden
+    from utils import metrics_DC as M
+    ops = load_golden("ops")
+    p = torch.from_numpy(ops["loss_p"]).cuda().requires_grad_(True)
+    t = torch.from_numpy(ops["loss_t"]).cuda()
+    if gamma == 2.0:
+        loss = M.focal_dice_loss(p, t, alpha=1.0, gamma=2.0, ratio=0.3)
+        assert abs(loss.item() - float(ops["loss_val"])) < 1e-6
+        loss.backward()
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ops["loss_gp"], atol=1e-7, rtol=1e-4)
+    g = gen(23)
+    pr = torch.rand(3, 2, 40, 56, generator=g)
+    pr[0, 0, 0, :4] = torch.tensor([0.0, 1.0, 1e-30, 1 - 1e-7])          # log clamps
+    tg = (torch.rand(3, 2, 40, 56, generator=g) < 0.3).float()
+    a = pr.clone().cuda().requires_grad_(True)
+    b = pr.clone().cuda().requires_grad_(True)
+    lf = M.focal_dice_loss(a, tg.cuda(), alpha=0.75, gamma=gamma, ratio=0.4)
+    lt = 0.4 * M.FocalLoss(alpha=0.75, gamma=gamma)(b, tg.cuda()) + 0.6 * M.dice_loss(b, tg.cuda())
+    assert abs(lf.item() - lt.item()) < 2e-6 * max(1.0, abs(lt.item()))
+    (lf * 3.0).backward()
+    (lt * 3.0).backward()
+    fin = torch.isfinite(b.grad)
+    assert torch.equal(torch.isfinite(a.grad), fin)
+    assert float((a.grad[fin] - b.grad[fin]).abs().max()) < 1e-6 * float(b.grad[fin].abs().max()) + 1e-9

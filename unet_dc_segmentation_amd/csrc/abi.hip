@@ -295,6 +295,21 @@ int unetdc_head_bwd(const float* dprobs, const float* probs, const void* a, int 
   return launch_head_bwd(p, dw, db, workspace, (long)workspace_bytes, dtype, (hipStream_t)s);
 }
 
+int64_t unetdc_focal_dice_loss_workspace(int nimg, int64_t hw) { return loss_workspace_bytes(nimg, (long)hw); }
+
+int unetdc_focal_dice_loss_fwd(const float* probs, const float* target, float* loss_out, float* coef, void* workspace,
+                               int64_t workspace_bytes, int nimg, int64_t hw, float alpha, float gamma, float ratio,
+                               float smooth, unetdc_stream_t s) {
+  return launch_loss_fwd(probs, target, loss_out, coef, workspace, (long)workspace_bytes, nimg, (long)hw, alpha, gamma,
+                         ratio, smooth, (hipStream_t)s);
+}
+
+int unetdc_focal_dice_loss_bwd(const float* probs, const float* target, const float* coef, const float* grad_out,
+                               float* dprobs, int nimg, int64_t hw, float alpha, float gamma, float ratio,
+                               unetdc_stream_t s) {
+  return launch_loss_bwd(probs, target, coef, grad_out, dprobs, nimg, (long)hw, alpha, gamma, ratio, (hipStream_t)s);
+}
+
 int64_t unetdc_channel_sum_workspace(int64_t npixels, int c) { return channel_sum_workspace_bytes((long)npixels, c); }
 
 int unetdc_channel_sum(const void* x, int ldx, float* out, void* workspace, int64_t workspace_bytes,

@@ -107,4 +107,10 @@ long channel_sum_workspace_bytes(long P, int C);
 int launch_channel_sum(const void* x, int ldx, float* out, void* workspace, long workspace_bytes, long P, int C,
                        int dtype, hipStream_t stream);
 
+long loss_workspace_bytes(int nimg, long hw);
+int launch_loss_fwd(const float* p, const float* t, float* loss_out, float* coef, void* workspace, long workspace_bytes,
+                    int nimg, long hw, float alpha, float gamma, float ratio, float smooth, hipStream_t stream);
+int launch_loss_bwd(const float* p, const float* t, const float* coef, const float* gout, float* dp, int nimg, long hw,
+                    float alpha, float gamma, float ratio, hipStream_t stream);
+
 }  // namespace unetdc

@@ -8,6 +8,8 @@ The seaborn confusion-matrix plot (:87-116) is reporting-only and out of scope (
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -54,7 +56,15 @@ class FocalLoss(nn.Module):
 
 
 def focal_dice_loss(pred, target, alpha=1.0, gamma=2.0, ratio=0.3):
-    """ratio * focal + (1 - ratio) * dice; train_DC_focal.py:222 uses (1.0, 2.0, 0.3)."""
+    """ratio * focal + (1 - ratio) * dice; train_DC_focal.py:222 uses (1.0, 2.0, 0.3).
+
+    fp32 probability maps on a HIP device take the fused kernels of
+    ``unet_dc_segmentation_amd/csrc/loss.hip`` (same arithmetic, three launches instead of ~25 ATen
+    ones); set UNETDC_FUSED_LOSS=0 to force the PyTorch formulation."""
+    if pred.is_cuda and os.environ.get("UNETDC_FUSED_LOSS", "1") != "0":
+        from unet_dc_segmentation_amd import loss as fused
+        if fused.supported(pred, target):
+            return fused.focal_dice_loss(pred, target, alpha, gamma, ratio)
     fl = FocalLoss(alpha=alpha, gamma=gamma, reduction="mean")(pred, target)
     return ratio * fl + (1 - ratio) * dice_loss(pred, target)
 
