@@ -30,8 +30,11 @@ import os
 ENCODER = ("enc1", "enc2", "enc3", "enc4")
 # fuse the BatchNorm-backward reduction into the dgrad epilogue that produces the gradient (A/B switch)
 FUSE_BN_BWD = os.environ.get("UNETDC_FUSE_BNBWD", "1") != "0"
-# run the weight-gradient kernels (off the backward critical chain) on a side HIP stream (A/B switch)
-SIDE_WGRAD = os.environ.get("UNETDC_SIDE_WGRAD", "1") != "0"
+# Opt-in (UNETDC_SIDE_WGRAD=1): run the weight-gradient kernels, which hang off the backward critical
+# chain, on a side HIP stream.  Measured +0.6 % on MI355X (the MFMA kernels fill the CUs' LDS, so little
+# co-residency with the HBM-bound BatchNorm passes); off by default because overlapping kernels make
+# per-kernel timings (bench.py roofline leg, rocprofv3) unattributable.
+SIDE_WGRAD = os.environ.get("UNETDC_SIDE_WGRAD", "0") == "1"
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
