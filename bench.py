@@ -183,7 +183,12 @@ def main():
 
     from unet_dc_segmentation_amd import _lib, dp as dpmod
     from utils.metrics_DC import focal_dice_loss
-    rank, local, world = dpmod.init_from_env("nccl")
+    # RCCL ("nccl") is the production backend; UNETDC_DIST_BACKEND=gloo + UNETDC_BENCH_DEVICE=0 lets several
+    # ranks rehearse the multi-rank code path on ONE card (RCCL refuses two ranks per device).
+    backend = os.environ.get("UNETDC_DIST_BACKEND", "nccl")
+    rank, local, world = dpmod.init_from_env(backend)
+    if "UNETDC_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["UNETDC_BENCH_DEVICE"])
     if world != args.gpus and rank == 0:
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a HIP device"

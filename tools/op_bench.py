@@ -2,6 +2,7 @@
 """Single-operator microbenchmark (for rocprofv3 --pmc runs): repeats one C-ABI conv call.
 
     python tools/op_bench.py fwd 8 512 512 64 64 1 bf16 [reps]
+    python tools/op_bench.py convt_fwd 8 256 256 128 64 1 bf16      (h, w = INPUT size; also convt_dgrad, convt_wgrad)
 """
 import os
 import sys
@@ -21,11 +22,31 @@ wf, wd = G.pack_conv(wt, dtype)
 y = torch.empty(n * h * w, cout, dtype=G.TD[dtype], device="cuda")
 dx = torch.empty(n * h * w, cin, dtype=G.TD[dtype], device="cuda")
 bias = torch.zeros(cout, device="cuda")
+DTI = G.DT[dtype]
+is_t = op.startswith("convt")
+if is_t:
+    wtt = torch.randn(cin, cout, 2, 2, generator=g) / (2 * cin ** 0.5)
+    twf, twd = G.pack_convT(wtt, dtype)
+    up = torch.empty(n * 4 * h * w, 2 * cout, dtype=G.TD[dtype], device="cuda")       # concat buffer, first half written
+    dup = torch.randn(n * 4 * h * w, 2 * cout, generator=g).to(G.TD[dtype]).cuda()
+    tdx = torch.empty(n * h * w, cin, dtype=G.TD[dtype], device="cuda")
+    tdw = torch.empty(cin, cout, 2, 2, device="cuda")
+    tws_bytes = _lib.load().unetdc_convT2x2_wgrad_workspace(n, h, w, cin, cout, G.DT[dtype])
+    tws = G.workspace(tws_bytes)
 
 
 def run():
     if op == "fwd":
         G.conv3x3_fwd(x, wf, bias, n, h, w, cin, cout, d, dtype, y, stats=True)
+    elif op == "convt_fwd":
+        _lib.call("unetdc_convT2x2_fwd", x.data_ptr(), cin, twf.data_ptr(), bias.data_ptr(), up.data_ptr(), 2 * cout,
+                  n, h, w, cin, cout, DTI, G.stream())
+    elif op == "convt_dgrad":
+        _lib.call("unetdc_convT2x2_dgrad", dup.data_ptr(), 2 * cout, twd.data_ptr(), tdx.data_ptr(), cin,
+                  n, h, w, cin, cout, DTI, G.stream())
+    elif op == "convt_wgrad":
+        _lib.call("unetdc_convT2x2_wgrad", x.data_ptr(), cin, dup.data_ptr(), 2 * cout, tdw.data_ptr(), tws.data_ptr(),
+                  tws_bytes, n, h, w, cin, cout, DTI, G.stream())
     elif op == "dgrad":
         G.conv3x3_dgrad(dy, wd, dx, n, h, w, cin, cout, d, dtype)
     else:
@@ -42,6 +63,6 @@ for _ in range(reps):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
-fl = 2.0 * n * h * w * cin * cout * 9
+fl = 2.0 * n * h * w * cin * cout * (4 if is_t else 9)
 print(f"{op} {n}x{h}x{w} {cin}->{cout} d={d} {dtype}: {ms * 1e3:.1f} us  {fl / ms / 1e9:.1f} TFLOP/s "
       f"(UNETDC_IGEMM={os.environ.get('UNETDC_IGEMM', '')})")

@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["abi.hip", "igemm_conv.hip", "igemm_dma.hip", "igemm_halo.hip", "wgrad.hip", "wgrad_dma.hip", "wgrad_fused.hip", "first_conv.hip", "elementwise.hip", "loss.hip"]
-HEADERS = ["common.h", "kernels.h", "wgrad_frag.h", os.path.join("..", "..", "include", "unetdc_hip.h")]
+HEADERS = ["common.h", "kernels.h", "wgrad_frag.h", "igemm_epilogue.h", os.path.join("..", "..", "include", "unetdc_hip.h")]
 OUT = os.path.join(HERE, "libunetdc_hip.so")
 
 
@@ -31,8 +31,11 @@ def needs_build():
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return OUT
+    # -fno-slp-vectorize: keeps the channel-pair arithmetic scalar (no v_pk_*_f32).  The packed build of the
+    # fused BatchNorm-backward epilogue was not run-to-run deterministic on MI355X (csrc/igemm_epilogue.h,
+    # BUILD NOTE); the scalar build is, and measures the same speed.
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", *[os.path.join(CSRC, f) for f in SOURCES], "-o", OUT]
+           "-Wno-unused-function", "-fno-slp-vectorize", *[os.path.join(CSRC, f) for f in SOURCES], "-o", OUT]
     if verbose:
         print("[unetdc build]", " ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -337,6 +337,14 @@ int launch_igemm(IgemmParams& p, int dtype, hipStream_t stream) {
   if (p.mode == MODE_AFFINE_RELU) UNETDC_REQUIRE(p.scale && p.shift, "igemm: scale/shift missing");
   if (p.mode == MODE_BNBWD)
     UNETDC_REQUIRE(p.stats && p.bn_y && p.scale && p.shift && p.bn_mean && p.bn_rstd, "igemm: BN-backward inputs missing");
+  {
+    const long howo = (long)p.Ho * p.Wo;
+    static int no_p2 = -1;                       // UNETDC_NO_P2=1: take the division paths everywhere (debugging)
+    if (no_p2 < 0) no_p2 = getenv("UNETDC_NO_P2") ? 1 : 0;
+    const bool p2 = !no_p2 && (p.Wo & (p.Wo - 1)) == 0 && (howo & (howo - 1)) == 0;
+    p.wo_shift = p2 ? __builtin_ctz((unsigned)p.Wo) : -1;
+    p.howo_shift = p2 ? __builtin_ctzl((unsigned long)howo) : -1;
+  }
   if (igemm_choice() == 0 && igemm_halo_supported(p, dtype)) return launch_igemm_halo(p, dtype, stream);
   if (!use_legacy() && igemm_dma_supported(p, dtype)) return launch_igemm_dma(p, dtype, stream);
   if (p.mode == MODE_BNBWD) return UNETDC_EUNSUPPORTED;      // first-generation kernel: caller reduces separately

@@ -15,7 +15,9 @@
 // Pipeline: two LDS stages, ONE barrier per K-step:  wait(my DMAs of step s) ; barrier ;
 // issue DMAs of step s+1 into the other stage ; ds_read + MFMA on stage s.
 #include <stdio.h>
+#include <stdlib.h>
 
+#include "igemm_epilogue.h"
 #include "kernels.h"
 
 namespace unetdc {
@@ -77,19 +79,53 @@ __global__ __launch_bounds__(512, 2) void igemm_dma_kernel(const IgemmParams p) 
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, wbytes, 0x00020000);
 
+  // pixel index -> (image, y, x): shifts when the map sizes are powers of two (every U-Net level), else divisions
+  const bool p2 = p.wo_shift >= 0;
+  auto decode = [&](int m, int& n, int& oy, int& ox) {
+    if (p2) {
+      n = m >> p.howo_shift;
+      const int rem = m & (HoWo - 1);
+      oy = rem >> p.wo_shift;
+      ox = rem & (p.Wo - 1);
+    } else {
+      n = m / HoWo;
+      const int rem = m - n * HoWo;
+      oy = rem / p.Wo;
+      ox = rem - oy * p.Wo;
+    }
+  };
+  // ---- taps that can touch the image for ANY row of this block (wave-uniform, conservative): a block is a
+  // segment of one image row, or whole rows of one image, or spans images
+  unsigned tapmask = 0;
+  {
+    int na, ya, xa, nb, yb, xb;
+    const int mlast = (m0 + BM < p.M ? m0 + BM : p.M) - 1;
+    decode(m0, na, ya, xa);
+    decode(mlast, nb, yb, xb);
+    int by0 = 0, by1 = p.Ho - 1, bx0 = 0, bx1 = p.Wo - 1;
+    if (na == nb) {
+      by0 = ya; by1 = yb;
+      if (ya == yb) { bx0 = xa; bx1 = xb; }
+    }
+    for (int t = 0; t < p.ntaps; ++t) {
+      const int iy0 = by0 * p.stride + p.offy[t], iy1 = by1 * p.stride + p.offy[t];
+      const int ix0 = bx0 * p.stride + p.offx[t], ix1 = bx1 * p.stride + p.offx[t];
+      if (iy1 >= 0 && iy0 < p.Hi && ix1 >= 0 && ix0 < p.Wi) tapmask |= 1u << t;
+    }
+    tapmask = __builtin_amdgcn_readfirstlane(tapmask);
+  }
   // ---- per-lane description of the A rows this lane feeds (row = 8*instr + lane/8) -------------
   const int sub = lane >> 3, pc = lane & 7;
   int ys[AI], xs[AI];
   unsigned abase[AI];                            // byte offset of (pixel, swizzled chunk) at tap 0,0 / kc 0
-  unsigned tapmask = 0;
 #pragma unroll
   for (int j = 0; j < AI; ++j) {
     const int row = (wave + NW * j) * 8 + sub;
     const int m = m0 + row;
     const int c = pc ^ ((row >> 1) & 7);
     if (m < p.M) {
-      const int n = m / HoWo, rem = m - n * HoWo;
-      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      int n, oy, ox;
+      decode(m, n, oy, ox);
       ys[j] = oy * p.stride;
       xs[j] = ox * p.stride;
       abase[j] = (unsigned)(((n * p.Hi + ys[j]) * p.Wi + xs[j]) * p.ldx * ES + c * 16);
@@ -97,10 +133,6 @@ __global__ __launch_bounds__(512, 2) void igemm_dma_kernel(const IgemmParams p) 
       ys[j] = -(1 << 28);
       xs[j] = 0;
       abase[j] = 0;
-    }
-    for (int t = 0; t < p.ntaps; ++t) {
-      const int iy = ys[j] + p.offy[t], ix = xs[j] + p.offx[t];
-      if ((unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) tapmask |= 1u << t;
     }
   }
   // B rows: LDS row lrow holds output channel grp*64 + 2*(q&31) + (q>>5) (even channels first)
@@ -112,15 +144,6 @@ __global__ __launch_bounds__(512, 2) void igemm_dma_kernel(const IgemmParams p) 
     const int cc = (q & 31) * 2 + (q >> 5);
     const int c = pc ^ ((lrow >> 1) & 7);
     bbase[j] = (unsigned)((n0 + grp * 64 + cc) * p.Cin * ES + c * 16);
-  }
-  {
-    unsigned* sm_u = reinterpret_cast<unsigned*>(smem);
-    if (tid == 0) sm_u[0] = 0;
-    __syncthreads();
-    if (tapmask) atomicOr(&sm_u[0], tapmask);
-    __syncthreads();
-    tapmask = sm_u[0];
-    __syncthreads();
   }
   const int nkc = p.Cin / KE;
   const int nsteps = __popc(tapmask) * nkc;
@@ -189,117 +212,105 @@ __global__ __launch_bounds__(512, 2) void igemm_dma_kernel(const IgemmParams p) 
     }
   }
 
-  // ---- epilogue: straight from the accumulators -----------------------------------------------
+  // ---- epilogue: straight from the accumulators (igemm_epilogue.h) --------------------------------
   const int col = n0 + wn * 64 + 2 * r;
-  T* __restrict__ og = reinterpret_cast<T*>(p.out);
-  float k0a = 0.f, k0b = 0.f, k1a = 0.f, k1b = 0.f;
-  int shuf_ab = 0, shuf_co = col;
-  if (p.mode == MODE_AFFINE_RELU) {
-    k0a = p.scale[col]; k0b = p.scale[col + 1];
-    k1a = p.shift[col]; k1b = p.shift[col + 1];
-  } else if (p.mode == MODE_SHUFFLE) {
-    shuf_ab = col / p.shuf_c;
-    shuf_co = col - shuf_ab * p.shuf_c;
-    if (p.bias) { k1a = p.bias[shuf_co]; k1b = p.bias[shuf_co + 1]; }
-  } else if (p.mode == MODE_BNBWD) {
-    k0a = p.scale[col]; k0b = p.scale[col + 1];
-    k1a = p.shift[col]; k1b = p.shift[col + 1];
-  } else if (p.bias) {
-    k1a = p.bias[col]; k1b = p.bias[col + 1];
-  }
-  float mua = 0.f, mub = 0.f, rsa = 0.f, rsb = 0.f;
-  if (p.mode == MODE_BNBWD) {
-    mua = p.bn_mean[col]; mub = p.bn_mean[col + 1];
-    rsa = p.bn_rstd[col]; rsb = p.bn_rstd[col + 1];
-  }
-  const T* __restrict__ yg = reinterpret_cast<const T*>(p.bn_y);
-  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-  const bool fastrow = (p.Wo & 31) == 0;        // a 32-row MFMA tile then lies inside one image row
+  float st[4] = {0.f, 0.f, 0.f, 0.f};
+  // fast path: whole 32-row MFMA tiles inside the tensor (and, for the pixel shuffle, inside one image row)
+  const bool fast = (p.M & 31) == 0 && (p.mode != MODE_SHUFFLE || (p.Wo & 31) == 0);
+  if (fast) {
+    const unsigned ldob = (unsigned)(p.ldo * ES), ldyb = (unsigned)(p.bn_ldy * ES);
+    bool tile_ok[TM];
+    unsigned voff[TM], yoff[TM];
+    int ccol = col;
+    unsigned row_bytes = ldob;
+    if (p.mode == MODE_SHUFFLE) {
+      const int ab = col / p.shuf_c;
+      ccol = col - ab * p.shuf_c;
+      row_bytes = 2 * ldob;
 #pragma unroll
-  for (int mi = 0; mi < TM; ++mi) {
-    const int mb = m0 + (wm * TM + mi) * 32;
-    int bn = 0, boy = 0, box = 0;
-    if (p.mode == MODE_SHUFFLE && fastrow) {
-      bn = mb / HoWo;
-      const int rem = mb - bn * HoWo;
-      boy = rem / p.Wo;
-      box = rem - boy * p.Wo;
+      for (int mi = 0; mi < TM; ++mi) {
+        const int mb = m0 + (wm * TM + mi) * 32;
+        tile_ok[mi] = mb < p.M;
+        int n, oy, ox;
+        decode(mb, n, oy, ox);
+        const unsigned pix = (unsigned)((n * 2 * p.Ho + 2 * oy + (ab >> 1)) * (2 * p.Wo) + 2 * ox + (ab & 1));
+        voff[mi] = (pix + 8u * h) * ldob + (unsigned)(ccol * ES);
+        yoff[mi] = 0;
+      }
+    } else {
+#pragma unroll
+      for (int mi = 0; mi < TM; ++mi) {
+        const int mb = m0 + (wm * TM + mi) * 32;
+        tile_ok[mi] = mb < p.M;
+        voff[mi] = (unsigned)(mb + 4 * h) * ldob + (unsigned)(col * ES);
+        yoff[mi] = (unsigned)(mb + 4 * h) * ldyb + (unsigned)(col * ES);
+      }
     }
-    // BN-backward fusion: fetch this tile's 16 (y, y+1) pairs up front so the loads overlap each other
-    typename PairRaw<T>::raw_t yraw[16];
+    switch (p.mode) {
+      case MODE_STATS: epilogue_tiles<T, MODE_STATS, TM>(p, acc, tile_ok, voff, row_bytes, yoff, ldyb, ccol, st); break;
+      case MODE_AFFINE_RELU: epilogue_tiles<T, MODE_AFFINE_RELU, TM>(p, acc, tile_ok, voff, row_bytes, yoff, ldyb, ccol, st); break;
+      case MODE_BNBWD: epilogue_tiles<T, MODE_BNBWD, TM>(p, acc, tile_ok, voff, row_bytes, yoff, ldyb, ccol, st); break;
+      default: epilogue_tiles<T, MODE_STORE, TM>(p, acc, tile_ok, voff, row_bytes, yoff, ldyb, ccol, st); break;
+    }
+  } else {
+    // ragged shapes (M not a multiple of 32, or a pixel shuffle whose rows are not multiples of 32): per-row checks
+    T* __restrict__ og = reinterpret_cast<T*>(p.out);
+    const T* __restrict__ yg = reinterpret_cast<const T*>(p.bn_y);
+    float k0a = 0.f, k0b = 0.f, k1a = 0.f, k1b = 0.f, mua = 0.f, mub = 0.f, rsa = 0.f, rsb = 0.f;
+    int shuf_ab = 0, shuf_co = col;
+    if (p.mode == MODE_AFFINE_RELU || p.mode == MODE_BNBWD) {
+      k0a = p.scale[col]; k0b = p.scale[col + 1];
+      k1a = p.shift[col]; k1b = p.shift[col + 1];
+    } else if (p.mode == MODE_SHUFFLE) {
+      shuf_ab = col / p.shuf_c;
+      shuf_co = col - shuf_ab * p.shuf_c;
+      if (p.bias) { k1a = p.bias[shuf_co]; k1b = p.bias[shuf_co + 1]; }
+    } else if (p.bias) {
+      k1a = p.bias[col]; k1b = p.bias[col + 1];
+    }
     if (p.mode == MODE_BNBWD) {
+      mua = p.bn_mean[col]; mub = p.bn_mean[col + 1];
+      rsa = p.bn_rstd[col]; rsb = p.bn_rstd[col + 1];
+    }
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+      const int mb = m0 + (wm * TM + mi) * 32;
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int m = mb + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        yraw[reg] = PairRaw<T>::load(yg + (long)(m < p.M ? m : 0) * p.bn_ldy + col);
-      }
-    }
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int roff = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-      const int m = mb + roff;
-      if (m >= p.M) continue;
-      float v0 = acc[mi][0][reg], v1 = acc[mi][1][reg];
-      if (p.mode == MODE_AFFINE_RELU) {
-        v0 = fmaxf(fmaf(v0, k0a, k1a), 0.f);
-        v1 = fmaxf(fmaf(v1, k0b, k1b), 0.f);
-        store_pair_d<T>(og + (long)m * p.ldo + col, v0, v1);
-      } else if (p.mode == MODE_SHUFFLE) {
-        v0 += k1a; v1 += k1b;
-        int n = bn, oy = boy, ox = box + roff;
-        if (!fastrow) {
-          n = m / HoWo;
-          const int rem = m - n * HoWo;
-          oy = rem / p.Wo;
-          ox = rem - oy * p.Wo;
-        }
-        const long dst = ((long)(n * 2 * p.Ho + 2 * oy + (shuf_ab >> 1)) * (2 * p.Wo) + 2 * ox + (shuf_ab & 1));
-        store_pair_d<T>(og + dst * p.ldo + shuf_co, v0, v1);
-      } else if (p.mode == MODE_BNBWD) {
-        store_pair_d<T>(og + (long)m * p.ldo + col, v0, v1);
-        float y0, y1;
-        PairRaw<T>::unpack(yraw[reg], y0, y1);
-        const float g0 = fmaf(y0, k0a, k1a) > 0.f ? round_through<T>(v0) : 0.f;
-        const float g1 = fmaf(y1, k0b, k1b) > 0.f ? round_through<T>(v1) : 0.f;
-        s0 += g0; q0 = fmaf(g0, (y0 - mua) * rsa, q0);
-        s1 += g1; q1 = fmaf(g1, (y1 - mub) * rsb, q1);
-      } else {
-        v0 += k1a; v1 += k1b;
-        store_pair_d<T>(og + (long)m * p.ldo + col, v0, v1);
-        if (p.mode == MODE_STATS) {
-          const float t0 = round_through<T>(v0), t1 = round_through<T>(v1);
-          s0 += t0; q0 = fmaf(t0, t0, q0);
-          s1 += t1; q1 = fmaf(t1, t1, q1);
+        if (m >= p.M) continue;
+        float v0 = acc[mi][0][reg], v1 = acc[mi][1][reg];
+        if (p.mode == MODE_AFFINE_RELU) {
+          v0 = fmaxf(fmaf(v0, k0a, k1a), 0.f);
+          v1 = fmaxf(fmaf(v1, k0b, k1b), 0.f);
+          store_pair_d<T>(og + (long)m * p.ldo + col, v0, v1);
+        } else if (p.mode == MODE_SHUFFLE) {
+          v0 += k1a; v1 += k1b;
+          int n, oy, ox;
+          decode(m, n, oy, ox);
+          const long dst = ((long)(n * 2 * p.Ho + 2 * oy + (shuf_ab >> 1)) * (2 * p.Wo) + 2 * ox + (shuf_ab & 1));
+          store_pair_d<T>(og + dst * p.ldo + shuf_co, v0, v1);
+        } else if (p.mode == MODE_BNBWD) {
+          store_pair_d<T>(og + (long)m * p.ldo + col, v0, v1);
+          float y0, y1;
+          PairRaw<T>::unpack(PairRaw<T>::load(yg + (long)m * p.bn_ldy + col), y0, y1);
+          const float g0 = fmaf(y0, k0a, k1a) > 0.f ? round_through<T>(v0) : 0.f;
+          const float g1 = fmaf(y1, k0b, k1b) > 0.f ? round_through<T>(v1) : 0.f;
+          st[0] += g0; st[1] = fmaf(g0, (y0 - mua) * rsa, st[1]);
+          st[2] += g1; st[3] = fmaf(g1, (y1 - mub) * rsb, st[3]);
+        } else {
+          v0 += k1a; v1 += k1b;
+          store_pair_d<T>(og + (long)m * p.ldo + col, v0, v1);
+          if (p.mode == MODE_STATS) {
+            const float t0 = round_through<T>(v0), t1 = round_through<T>(v1);
+            st[0] += t0; st[1] = fmaf(t0, t0, st[1]);
+            st[2] += t1; st[3] = fmaf(t1, t1, st[3]);
+          }
         }
       }
     }
   }
-  if (p.mode == MODE_STATS || p.mode == MODE_BNBWD) {
-    const int nrow = (p.mode == MODE_BNBWD) ? 3 : 2;          // BN-backward partials carry a third (zero) row
-    s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
-    s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
-    __syncthreads();                                         // all waves are done with the stage buffers
-    float* red = reinterpret_cast<float*>(smem);             // [wave][4][32]
-    if (h == 0) {
-      red[(wave * 4 + 0) * 32 + r] = s0;
-      red[(wave * 4 + 1) * 32 + r] = q0;
-      red[(wave * 4 + 2) * 32 + r] = s1;
-      red[(wave * 4 + 3) * 32 + r] = q1;
-    }
-    __syncthreads();
-    if (tid < BN) {
-      const int wn2 = tid >> 6, c2 = tid & 63, r2 = c2 >> 1, e = c2 & 1;
-      float su = 0.f, sq = 0.f;
-#pragma unroll
-      for (int w2 = 0; w2 < WM; ++w2) {
-        su += red[((w2 * WN + wn2) * 4 + e * 2 + 0) * 32 + r2];
-        sq += red[((w2 * WN + wn2) * 4 + e * 2 + 1) * 32 + r2];
-      }
-      p.stats[((long)mblk * nrow + 0) * p.Cout + n0 + tid] = su;
-      p.stats[((long)mblk * nrow + 1) * p.Cout + n0 + tid] = sq;
-      if (nrow == 3) p.stats[((long)mblk * 3 + 2) * p.Cout + n0 + tid] = 0.f;
-    }
-  }
+  if (p.mode == MODE_STATS || p.mode == MODE_BNBWD) write_stat_rows<WM, WN>(p, smem, st, mblk, n0, tid, wave, r, h);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -336,14 +347,26 @@ bool igemm_dma_supported(const IgemmParams& p, int dtype) {
   const long HoWo = (long)p.Ho * p.Wo;
   const long xbytes = (p.M / HoWo) * p.Hi * p.Wi * p.ldx * es;
   const long wbytes = (long)p.ntaps * p.Cout * p.Cin * es;
-  return xbytes < (1L << 31) && wbytes < (1L << 31) && p.M % HoWo == 0;
+  const long opix = p.mode == MODE_SHUFFLE ? 4L * p.M : (long)p.M;
+  const long obytes = opix * p.ldo * es, ybytes = p.mode == MODE_BNBWD ? (long)p.M * p.bn_ldy * es : 0;
+  return xbytes < (1L << 31) && wbytes < (1L << 31) && obytes < (1L << 32) && ybytes < (1L << 32) && p.M % HoWo == 0;
 }
 
 int launch_igemm_dma(IgemmParams& p, int dtype, hipStream_t stream) {
-  if (p.Cout % 256 == 0 && p.M >= 256 * 64) {
+  static int force = -1;                        // UNETDC_DMA_CFG=A|B|C forces a tile configuration (experiments)
+  if (force < 0) {
+    const char* e = getenv("UNETDC_DMA_CFG");
+    force = e ? (e[0] == 'A' ? 1 : (e[0] == 'B' ? 2 : (e[0] == 'C' ? 3 : 0))) : 0;
+  }
+  // 256x256 tiles only when they still give every CU a workgroup; small maps (bottleneck: 8192 pixels)
+  // take 256x128 so that the grid covers the chip
+  const long blocks_a = (long)((p.M + 255) / 256) * (p.Cout / 256);
+  const bool use_a = (force == 1) || (force == 0 && p.Cout % 256 == 0 && p.M >= 256 * 64 && blocks_a >= 200);
+  const bool use_b = (force == 2) || (force == 0 && !use_a && p.Cout % 128 == 0);
+  if (use_a && p.Cout % 256 == 0) {
     return dtype == UNETDC_BF16 ? launch_dma_cfg<bf16_t, 2, 4, 4>(p, stream) : launch_dma_cfg<float, 2, 4, 4>(p, stream);
   }
-  if (p.Cout % 128 == 0) {
+  if (use_b && p.Cout % 128 == 0) {
     return dtype == UNETDC_BF16 ? launch_dma_cfg<bf16_t, 4, 2, 2>(p, stream) : launch_dma_cfg<float, 4, 2, 2>(p, stream);
   }
   return dtype == UNETDC_BF16 ? launch_dma_cfg<bf16_t, 4, 1, 2>(p, stream) : launch_dma_cfg<float, 4, 1, 2>(p, stream);

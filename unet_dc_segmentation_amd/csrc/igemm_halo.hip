@@ -18,6 +18,7 @@
 //     BN+ReLU (eval).
 #include <stdio.h>
 
+#include "igemm_epilogue.h"
 #include "kernels.h"
 
 namespace unetdc {
@@ -39,16 +40,6 @@ template <> struct MmaH<float> {
   }
 };
 
-template <typename T> __device__ __forceinline__ void store_pair_h(T* dst, float v0, float v1);
-template <> __device__ __forceinline__ void store_pair_h<float>(float* dst, float v0, float v1) {
-  *reinterpret_cast<float2*>(dst) = make_float2(v0, v1);
-}
-template <> __device__ __forceinline__ void store_pair_h<bf16_t>(bf16_t* dst, float v0, float v1) {
-  bf16_t lo = (bf16_t)v0, hi = (bf16_t)v1;
-  *reinterpret_cast<unsigned int*>(dst) = (unsigned int)__builtin_bit_cast(unsigned short, lo) |
-                                          ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
-}
-
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 constexpr unsigned HOOB = 0x80000000u;
 constexpr int TH = 8, TW = 32;                  // output tile in pixels
@@ -56,7 +47,7 @@ constexpr int MAXPJ = 14;                       // patch DMA instructions per wa
 
 // WN = 1: 4 waves (4 x 1), BN = 64;   WN = 2: 8 waves (4 x 2), BN = 128.  Wave tile 64 x 64.
 template <typename T, int WN>
-__global__ __launch_bounds__(512, 2) void igemm_halo_kernel(const IgemmParams p, int d, int npatch_bufs) {
+__global__ __launch_bounds__(512, 2) void igemm_halo_kernel(const IgemmParams p, int d, int npatch_bufs, int rcp_pw) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NW = 4 * WN;
   constexpr int BN = 64 * WN;
@@ -76,10 +67,21 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(const IgemmParams p,
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int mtile = tile / p.nblocks, nblk = tile - mtile * p.nblocks;
   const int n0 = nblk * BN;
-  const int tiles_x = p.Wo / TW, tiles_y = p.Ho / TH;
-  const int img = mtile / (tiles_x * tiles_y);
-  const int trem = mtile - img * tiles_x * tiles_y;
-  const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+  // tile -> (image, y0, x0): shifts when the map is a power of two in both directions
+  int img, y0, x0;
+  if (p.wo_shift >= 0) {
+    const int txs = p.wo_shift - 5, tis = p.howo_shift - 8;      // log2(tiles per row), log2(tiles per image)
+    img = mtile >> tis;
+    const int trem = mtile & ((1 << tis) - 1);
+    y0 = (trem >> txs) * TH;
+    x0 = (trem & ((1 << txs) - 1)) * TW;
+  } else {
+    const int tiles_x = p.Wo / TW, tiles_y = p.Ho / TH;
+    img = mtile / (tiles_x * tiles_y);
+    const int trem = mtile - img * tiles_x * tiles_y;
+    y0 = (trem / tiles_x) * TH;
+    x0 = (trem % tiles_x) * TW;
+  }
 
   const unsigned xbytes = (unsigned)(((long)p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.ldx * ES);
   const unsigned wbytes = (unsigned)((long)9 * p.Cout * p.Cin * ES);
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(const IgemmParams p,
 #pragma unroll
   for (int j = 0; j < MAXPJ; ++j) {
     const int pr = (wave + NW * j) * 8 + sub;
-    const int py = pr / PW, px = pr - py * PW;
+    const int py = (pr * rcp_pw) >> 16, px = pr - py * PW;       // exact for pr < 65536 / PW (host-checked)
     const int gy = y0 - d + py, gx = x0 - d + px;
     const bool ok = pr < PP && (unsigned)gy < (unsigned)p.Hi && (unsigned)gx < (unsigned)p.Wi;
     const int c = pc ^ ((pr >> 1) & 7);
@@ -183,89 +185,26 @@ __global__ __launch_bounds__(512, 2) void igemm_halo_kernel(const IgemmParams p,
     }
   }
 
-  // ---- epilogue -----------------------------------------------------------------------------------
+  // ---- epilogue (igemm_epilogue.h): an MFMA tile is 32 consecutive pixels of one image row ---------
   const int col = n0 + wn * 64 + 2 * r;
-  T* __restrict__ og = reinterpret_cast<T*>(p.out);
-  float k0a = 0.f, k0b = 0.f, k1a = 0.f, k1b = 0.f;
-  if (p.mode == MODE_AFFINE_RELU) {
-    k0a = p.scale[col]; k0b = p.scale[col + 1];
-    k1a = p.shift[col]; k1b = p.shift[col + 1];
-  } else if (p.mode == MODE_BNBWD) {
-    k0a = p.scale[col]; k0b = p.scale[col + 1];
-    k1a = p.shift[col]; k1b = p.shift[col + 1];
-  } else if (p.bias) {
-    k1a = p.bias[col]; k1b = p.bias[col + 1];
-  }
-  float mua = 0.f, mub = 0.f, rsa = 0.f, rsb = 0.f;
-  if (p.mode == MODE_BNBWD) {
-    mua = p.bn_mean[col]; mub = p.bn_mean[col + 1];
-    rsa = p.bn_rstd[col]; rsb = p.bn_rstd[col + 1];
-  }
-  const T* __restrict__ yg = reinterpret_cast<const T*>(p.bn_y);
-  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+  const unsigned ldob = (unsigned)(p.ldo * ES), ldyb = (unsigned)(p.bn_ldy * ES);
+  bool tile_ok[2];
+  unsigned voff[2], yoff[2];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
-    const long rowpix = ((long)img * p.Ho + y0 + wm * 2 + mi) * p.Wo + x0;
-    typename PairRaw<T>::raw_t yraw[16];
-    if (p.mode == MODE_BNBWD) {
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg)
-        yraw[reg] = PairRaw<T>::load(yg + (rowpix + (reg & 3) + 8 * (reg >> 2) + 4 * h) * p.bn_ldy + col);
-    }
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int tx = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-      float v0 = acc[mi][0][reg], v1 = acc[mi][1][reg];
-      T* dst = og + (rowpix + tx) * p.ldo + col;
-      if (p.mode == MODE_AFFINE_RELU) {
-        v0 = fmaxf(fmaf(v0, k0a, k1a), 0.f);
-        v1 = fmaxf(fmaf(v1, k0b, k1b), 0.f);
-        store_pair_h<T>(dst, v0, v1);
-      } else if (p.mode == MODE_BNBWD) {
-        store_pair_h<T>(dst, v0, v1);
-        float y0, y1;
-        PairRaw<T>::unpack(yraw[reg], y0, y1);
-        const float g0 = fmaf(y0, k0a, k1a) > 0.f ? round_through<T>(v0) : 0.f;
-        const float g1 = fmaf(y1, k0b, k1b) > 0.f ? round_through<T>(v1) : 0.f;
-        s0 += g0; q0 = fmaf(g0, (y0 - mua) * rsa, q0);
-        s1 += g1; q1 = fmaf(g1, (y1 - mub) * rsb, q1);
-      } else {
-        v0 += k1a; v1 += k1b;
-        store_pair_h<T>(dst, v0, v1);
-        if (p.mode == MODE_STATS) {
-          const float t0 = round_through<T>(v0), t1 = round_through<T>(v1);
-          s0 += t0; q0 = fmaf(t0, t0, q0);
-          s1 += t1; q1 = fmaf(t1, t1, q1);
-        }
-      }
-    }
+    const unsigned rowpix = (unsigned)(((img * p.Ho + y0 + wm * 2 + mi) * p.Wo) + x0 + 4 * h);
+    tile_ok[mi] = true;
+    voff[mi] = rowpix * ldob + (unsigned)(col * ES);
+    yoff[mi] = rowpix * ldyb + (unsigned)(col * ES);
   }
-  if (p.mode == MODE_STATS || p.mode == MODE_BNBWD) {
-    const int nrow = (p.mode == MODE_BNBWD) ? 3 : 2;
-    s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
-    s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);             // [wave][4][32]
-    if (h == 0) {
-      red[(wave * 4 + 0) * 32 + r] = s0;
-      red[(wave * 4 + 1) * 32 + r] = q0;
-      red[(wave * 4 + 2) * 32 + r] = s1;
-      red[(wave * 4 + 3) * 32 + r] = q1;
-    }
-    __syncthreads();
-    if (tid < BN) {
-      const int wn2 = tid >> 6, c2 = tid & 63, r2 = c2 >> 1, e = c2 & 1;
-      float su = 0.f, sq = 0.f;
-#pragma unroll
-      for (int w2 = 0; w2 < 4; ++w2) {
-        su += red[((w2 * WN + wn2) * 4 + e * 2 + 0) * 32 + r2];
-        sq += red[((w2 * WN + wn2) * 4 + e * 2 + 1) * 32 + r2];
-      }
-      p.stats[((long)mtile * nrow + 0) * p.Cout + n0 + tid] = su;
-      p.stats[((long)mtile * nrow + 1) * p.Cout + n0 + tid] = sq;
-      if (nrow == 3) p.stats[((long)mtile * 3 + 2) * p.Cout + n0 + tid] = 0.f;
-    }
+  float st[4] = {0.f, 0.f, 0.f, 0.f};
+  switch (p.mode) {
+    case MODE_STATS: epilogue_tiles<T, MODE_STATS, 2>(p, acc, tile_ok, voff, ldob, yoff, ldyb, col, st); break;
+    case MODE_AFFINE_RELU: epilogue_tiles<T, MODE_AFFINE_RELU, 2>(p, acc, tile_ok, voff, ldob, yoff, ldyb, col, st); break;
+    case MODE_BNBWD: epilogue_tiles<T, MODE_BNBWD, 2>(p, acc, tile_ok, voff, ldob, yoff, ldyb, col, st); break;
+    default: epilogue_tiles<T, MODE_STORE, 2>(p, acc, tile_ok, voff, ldob, yoff, ldyb, col, st); break;
   }
+  if (p.mode == MODE_STATS || p.mode == MODE_BNBWD) write_stat_rows<4, WN>(p, smem, st, mtile, n0, tid, wave, r, h);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -281,7 +220,8 @@ bool igemm_halo_supported(const IgemmParams& p, int dtype) {
   if ((long)p.M < 256L * 512) return false;      // small maps: not worth a patch per tile
   const long es = dtype == UNETDC_BF16 ? 2 : 4;
   const long xbytes = ((long)p.M / ((long)p.Ho * p.Wo)) * p.Hi * p.Wi * p.ldx * es;
-  return xbytes < (1L << 31);
+  const long obytes = (long)p.M * p.ldo * es, ybytes = p.mode == MODE_BNBWD ? (long)p.M * p.bn_ldy * es : 0;
+  return xbytes < (1L << 31) && obytes < (1L << 32) && ybytes < (1L << 32);
 }
 
 template <typename T, int WN>
@@ -307,7 +247,8 @@ static int launch_halo_cfg(IgemmParams& p, int d, hipStream_t stream) {
   p.mblocks = (int)((long)p.M / 256);
   p.nblocks = p.Cout / (64 * WN);
   const long nwg = (long)p.mblocks * p.nblocks;
-  hipLaunchKernelGGL((igemm_halo_kernel<T, WN>), dim3((unsigned)nwg), dim3(256 * WN), lds, stream, p, d, nbuf);
+  const int rcp_pw = (65536 + (TW + 2 * d) - 1) / (TW + 2 * d);     // pr / PW == (pr * rcp_pw) >> 16 for pr < 1024 (PW <= 36)
+  hipLaunchKernelGGL((igemm_halo_kernel<T, WN>), dim3((unsigned)nwg), dim3(256 * WN), lds, stream, p, d, nbuf, rcp_pw);
   char nm[96];
   snprintf(nm, sizeof(nm), "igemm_halo_kernel<%s, %d>", sizeof(T) == 2 ? "__bf16" : "float", WN);
   note_kernel(nm);

@@ -24,6 +24,7 @@ struct IgemmParams {
   int bn_ldy;
   int M, Ho, Wo, Hi, Wi, Cin, Cout, ldx, ldo, ntaps, stride, mode, shuf_c;
   int mblocks, nblocks;
+  int wo_shift, howo_shift;  // log2(Wo), log2(Ho*Wo) when both are powers of two, else -1 (set by launch_igemm)
   int offy[9];
   int offx[9];
 };

@@ -14,7 +14,8 @@ contiguous slices.  Slices are merged into buckets of ``bucket_bytes`` and all-r
 after waiting for the work already enqueued on the compute stream, so communication of
 decoder/bottleneck gradients overlaps the encoder backward kernels; ``finish()`` makes the compute
 stream wait for the outstanding collectives before autograd hands the gradients to the optimizer.
-Large buckets (default 32 MiB) keep each xGMI link busy with few, large messages.
+Buckets of >= 16 MiB keep each xGMI link busy with few, large messages while leaving only the last
+~1 MB (enc2 + enc1 gradients) to be reduced after the backward pass has finished.
 """
 from __future__ import annotations
 
@@ -23,7 +24,7 @@ import torch.distributed as dist
 
 
 class DataParallel:
-    def __init__(self, model, process_group=None, bucket_bytes=32 << 20, broadcast=True):
+    def __init__(self, model, process_group=None, bucket_bytes=16 << 20, broadcast=True):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed must be initialised (backend 'nccl' = RCCL on ROCm, or 'gloo')")
         self.model = model
