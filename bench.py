@@ -73,6 +73,9 @@ def igemm_flops(name, a, es=2):
     if name == "unetdc_convT2x2_dgrad_bnstats":
         n, h, w, cin, cout = a[14:19]
         return 2.0 * n * h * w * cin * 4 * cout, (n * h * w * (2 * cin + 4 * cout) + 4 * cin * cout) * es
+    if name == "unetdc_conv3x3_dgrad_colsum":          # dgrad + per-channel sums of its output (no extra traffic)
+        n, h, w, cin, cout = a[10:15]
+        return 2.0 * n * h * w * cout * cin * 9, (n * h * w * (cin + cout) + 9 * cin * cout) * es
     raise KeyError(name)
 
 
@@ -125,7 +128,7 @@ def per_layer_table(step, args):
         fl, shape = 0.0, ""
         ints = [v for v in a if isinstance(v, int) and 0 < v < 100000]
         if name in ("unetdc_conv3x3_fwd", "unetdc_conv3x3_dgrad", "unetdc_convT2x2_fwd", "unetdc_convT2x2_dgrad",
-                    "unetdc_conv3x3_dgrad_bnstats", "unetdc_convT2x2_dgrad_bnstats"):
+                    "unetdc_conv3x3_dgrad_bnstats", "unetdc_convT2x2_dgrad_bnstats", "unetdc_conv3x3_dgrad_colsum"):
             fl, _ = igemm_flops(name, a)
         elif name == "unetdc_conv3x3_wgrad":
             n, h, w, cin, cout = a[7:12]
@@ -228,7 +231,7 @@ def main():
     for _ in range(args.warmup):
         step()
     igemm_calls = ["unetdc_conv3x3_fwd", "unetdc_conv3x3_dgrad", "unetdc_convT2x2_fwd", "unetdc_convT2x2_dgrad",
-                   "unetdc_conv3x3_dgrad_bnstats", "unetdc_convT2x2_dgrad_bnstats"]
+                   "unetdc_conv3x3_dgrad_bnstats", "unetdc_convT2x2_dgrad_bnstats", "unetdc_conv3x3_dgrad_colsum"]
     if args.per_layer:
         per_layer_table(step, args)
     if world > 1:

@@ -177,6 +177,15 @@ int unetdc_focal_dice_loss_bwd(const float* probs, const float* target, const fl
                                float* dprobs, int nimg, int64_t hw, float alpha, float gamma, float ratio,
                                unetdc_stream_t s);
 
+/* conv3x3_dgrad that also returns colsum[i] = sum over pixels of the STORED dx[:, c0 + i], i < c (fp32).
+ * The decoder's first conv writes the gradient of torch.cat([up, enc]) (models/model_2.py:68,71,74,77); the
+ * column sums of its first half are the ConvTranspose2d bias gradient (:20,23,26,29), so that gradient costs
+ * no extra pass over the tensor. */
+int64_t unetdc_conv3x3_dgrad_colsum_workspace(int n, int h, int w, int cin);
+int unetdc_conv3x3_dgrad_colsum(const void* dy, int lddy, const void* w_dgrad, void* dx, int lddx, float* colsum, int c0,
+                                int c, void* workspace, int64_t workspace_bytes, int n, int h, int w, int cin, int cout,
+                                int dilation, int dtype, unetdc_stream_t s);
+
 /* ---- per-channel column sum of an NHWC tensor (ConvTranspose2d bias gradient) ------------------ */
 int64_t unetdc_channel_sum_workspace(int64_t npixels, int c);
 int unetdc_channel_sum(const void* x, int ldx, float* out, void* workspace, int64_t workspace_bytes,

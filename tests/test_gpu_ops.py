@@ -389,6 +389,37 @@ def test_dgrad_with_fused_bn_backward_statistics(dtype, case):
     assert rel(outs[1][1], outs[0][1]) < 1e-4 and rel(outs[1][2], outs[0][2]) < 1e-4
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 16, 24, 128, 64, 1), (1, 64, 64, 256, 128, 1), (2, 256, 256, 128, 64, 1)])
+def test_dgrad_with_fused_column_sums(dtype, case):
+    """conv3x3_dgrad_colsum == conv3x3_dgrad (bitwise) + per-channel sums of the first half of the STORED result
+    (the ConvTranspose2d bias gradient, torch: dcat[:, :C].sum over pixels), fp64 check of the sums."""
+    n, h, w, cin, cout, d = case
+    g = gen(17)
+    P = n * h * w
+    dyv = G.to_nhwc(torch.randn(n, cout, h, w, generator=g), dtype)
+    _, wd = G.pack_conv(torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5), dtype)
+    dx0 = G.empty_nhwc(P, cin, dtype)
+    G.conv3x3_dgrad(dyv, wd, dx0, n, h, w, cin, cout, d, dtype)
+    dx1 = G.empty_nhwc(P, cin, dtype)
+    c = cin // 2
+    out = torch.full((c,), float("nan"), device="cuda")
+    nbytes = _lib.load().unetdc_conv3x3_dgrad_colsum_workspace(n, h, w, cin)
+    ws = G.workspace(nbytes)
+    call("unetdc_conv3x3_dgrad_colsum", dyv.data_ptr(), dyv.stride(0), wd.data_ptr(), dx1.data_ptr(), dx1.stride(0),
+         out.data_ptr(), 0, c, ws.data_ptr(), nbytes, n, h, w, cin, cout, d, G.DT[dtype], G.stream())
+    assert torch.equal(dx0.float(), dx1.float())
+    ref = dx1.double()[:, :c].sum(0).cpu()
+    scale = float(dx1.double()[:, :c].abs().sum(0).max())
+    assert float((out.cpu().double() - ref).abs().max()) <= 2e-6 * scale
+    # a column window that does not start at 0
+    out2 = torch.full((16,), float("nan"), device="cuda")
+    call("unetdc_conv3x3_dgrad_colsum", dyv.data_ptr(), dyv.stride(0), wd.data_ptr(), dx1.data_ptr(), dx1.stride(0),
+         out2.data_ptr(), cin - 16, 16, ws.data_ptr(), nbytes, n, h, w, cin, cout, d, G.DT[dtype], G.stream())
+    ref2 = dx1.double()[:, cin - 16:].sum(0).cpu()
+    assert float((out2.cpu().double() - ref2).abs().max()) <= 2e-6 * float(dx1.double().abs().sum(0).max())
+
+
 @pytest.mark.parametrize("case", [(8, 512, 512, 64, 64, 1), (8, 256, 256, 128, 128, 2), (8, 64, 64, 512, 512, 8),
                                   (8, 512, 512, 128, 64, 1)])
 def test_fused_bn_backward_statistics_are_run_to_run_deterministic(case):

@@ -53,6 +53,8 @@ SIGNATURES = {
     "unetdc_focal_dice_loss_workspace": (L, [I, L]),
     "unetdc_focal_dice_loss_fwd": (I, [P, P, P, P, P, L, I, L, F, F, F, F, P]),
     "unetdc_focal_dice_loss_bwd": (I, [P, P, P, P, P, I, L, F, F, F, P]),
+    "unetdc_conv3x3_dgrad_colsum_workspace": (L, [I, I, I, I]),
+    "unetdc_conv3x3_dgrad_colsum": (I, [P, I, P, P, I, P, I, I, P, L, I, I, I, I, I, I, I, P]),
     "unetdc_channel_sum_workspace": (L, [L, I]),
     "unetdc_channel_sum": (I, [P, I, P, P, L, L, I, I, P]),
 }

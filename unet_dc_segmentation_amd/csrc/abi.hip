@@ -91,6 +91,32 @@ int unetdc_conv3x3_dgrad(const void* dy, int lddy, const void* w_dgrad, void* dx
   return launch_igemm(p, dtype, (hipStream_t)s);
 }
 
+// dgrad whose epilogue also sums the stored gradient per channel: colsum[c] = sum_pixels dx[:, c0 + c]
+int64_t unetdc_conv3x3_dgrad_colsum_workspace(int n, int h, int w, int cin) {
+  return ((int64_t)igemm_mblocks((long)n * h * w, cin) + 64) * 2 * cin * 4;
+}
+
+int unetdc_conv3x3_dgrad_colsum(const void* dy, int lddy, const void* w_dgrad, void* dx, int lddx, float* colsum, int c0,
+                                int c, void* workspace, int64_t workspace_bytes, int n, int h, int w, int cin, int cout,
+                                int dilation, int dtype, unetdc_stream_t s) {
+  GEOM_CHECK(n, h, w);
+  UNETDC_REQUIRE(dilation >= 1, "conv3x3_dgrad_colsum: dilation must be >= 1");
+  UNETDC_REQUIRE(lddy >= cout && lddx >= cin, "conv3x3_dgrad_colsum: ld smaller than channel count");
+  UNETDC_REQUIRE(colsum && workspace && c0 >= 0 && c > 0 && c0 + c <= cin, "conv3x3_dgrad_colsum: bad column range");
+  if (workspace_bytes < unetdc_conv3x3_dgrad_colsum_workspace(n, h, w, cin)) {
+    set_error("conv3x3_dgrad_colsum: workspace too small (%ld bytes)", (long)workspace_bytes);
+    return UNETDC_EWORKSPACE;
+  }
+  IgemmParams p{};
+  p.x = dy; p.w = w_dgrad; p.out = dx;
+  p.M = n * h * w; p.Ho = h; p.Wo = w; p.Hi = h; p.Wi = w; p.Cin = cout; p.Cout = cin; p.ldx = lddy; p.ldo = lddx;
+  p.ntaps = 9; p.stride = 1; p.mode = MODE_STATS; p.stats = reinterpret_cast<float*>(workspace);
+  taps3x3(dilation, p.offy, p.offx);
+  int rc = launch_igemm(p, dtype, (hipStream_t)s);
+  if (rc != UNETDC_OK) return rc;
+  return launch_stats_colsum(p.stats, igemm_mblocks((long)p.M, cin), cin, c0, c, colsum, (hipStream_t)s);
+}
+
 // dgrad whose epilogue also produces the BatchNorm-backward partial sums of the stage that consumes dx
 static int dgrad_bnstats_common(IgemmParams& p, const void* y_prev, int ldy_prev, const float* scale,
                                 const float* shift, const float* mean, const float* rstd, float* parts,

@@ -803,6 +803,26 @@ int launch_channel_sum(const void* x, int ldx, float* out, void* workspace, long
   return check_launch("channel_sum_finalize_kernel");
 }
 
+// Column sums out of MODE_STATS partial rows [nparts][2][L/2 ... ] (row 0 of each pair = sums of the stored values):
+// out[c] = sum_rows parts[row][0][c0 + c].  Used for the ConvTranspose2d bias gradient, whose input (the first
+// half of the decoder's concat gradient) is written by the dgrad kernel that produced `parts`.
+__global__ void stats_colsum_finalize_kernel(const float* __restrict__ parts, int nparts, int L, int c0, float* out, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int i = 0; i < nparts; ++i) s += (double)parts[(long)i * L + c0 + c];
+  out[c] = (float)s;
+}
+
+int launch_stats_colsum(const float* parts, int nparts, int ctotal, int c0, int c, float* out, hipStream_t stream) {
+  UNETDC_REQUIRE(parts && out && nparts > 0 && c0 >= 0 && c > 0 && c0 + c <= ctotal, "stats_colsum: bad arguments");
+  const float* rp; int rows;
+  int rc = reduce_parts(parts, nparts, 2 * ctotal, &rp, &rows, stream);
+  if (rc != UNETDC_OK) return rc;
+  hipLaunchKernelGGL(stats_colsum_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, stream, rp, rows, 2 * ctotal, c0, out, c);
+  return check_launch("stats_colsum_finalize_kernel");
+}
+
 int launch_pack_many(const void* table_dev, int n, long total_tiles, int dtype, hipStream_t stream) {
   UNETDC_REQUIRE(table_dev && n > 0 && total_tiles > 0 && total_tiles < (1L << 31), "pack_many: empty table");
   UNETDC_REQUIRE(dtype == UNETDC_F32 || dtype == UNETDC_BF16, "pack_many: bad dtype %d", dtype);

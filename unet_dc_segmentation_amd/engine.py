@@ -30,6 +30,8 @@ import os
 ENCODER = ("enc1", "enc2", "enc3", "enc4")
 # fuse the BatchNorm-backward reduction into the dgrad epilogue that produces the gradient (A/B switch)
 FUSE_BN_BWD = os.environ.get("UNETDC_FUSE_BNBWD", "1") != "0"
+# ConvTranspose2d bias gradient = column sums of the concat gradient, produced by the dgrad epilogue that writes it
+FUSE_COLSUM = os.environ.get("UNETDC_FUSE_COLSUM", "1") != "0"
 # Opt-in (UNETDC_SIDE_WGRAD=1): run the weight-gradient kernels, which hang off the backward critical
 # chain, on a side HIP stream.  Measured +0.6 % on MI355X (the MFMA kernels fill the CUs' LDS, so little
 # co-residency with the HBM-bound BatchNorm passes); off by default because overlapping kernels make
@@ -171,6 +173,7 @@ class UNetEngine:
             h, w = self.res[lvl]
             need = max(need, lib.unetdc_convT2x2_wgrad_workspace(N, h, w, u["cin"], u["cout"], self.dt))
             need = max(need, lib.unetdc_channel_sum_workspace(self.npix[lvl - 1], u["cout"]))
+            need = max(need, lib.unetdc_conv3x3_dgrad_colsum_workspace(N, 2 * h, 2 * w, 2 * u["cout"]))
         need = max(need, lib.unetdc_head_bwd_workspace(N, H, W, 64, self.oc, self.dt))
         self.ws_bytes = int(need)
         self.workspace = None
@@ -359,11 +362,13 @@ class UNetEngine:
                 prev.mean.data_ptr(), prev.rstd.data_ptr(), prev.bwd_parts.data_ptr(), prev.bwd_parts.numel(),
                 __import__("ctypes").byref(self._np))
 
-    def _stage_bwd(self, st, flat, lvl, dskip, dpool, dx_out, fuse_prev=None):
+    def _stage_bwd(self, st, flat, lvl, dskip, dpool, dx_out, fuse_prev=None, colsum=None):
         """Backward of one stage.  dskip/dpool: incoming gradient(s) of the activation;
         dx_out: [npix, cin] view to receive the input gradient (None for the first stage);
         fuse_prev: the stage consuming dx_out as its activation gradient -- its BatchNorm-backward
-        reduction is then fused into this stage's dgrad epilogue."""
+        reduction is then fused into this stage's dgrad epilogue;
+        colsum: (fp32 out, c0, c) -- per-channel sums of dx_out[:, c0:c0+c] produced by the dgrad epilogue
+        (the ConvTranspose2d bias gradient when dx_out is the gradient of the concat buffer)."""
         s = _stream()
         N = self.N
         h, w = st.hw
@@ -392,15 +397,19 @@ class UNetEngine:
                      dx_out.data_ptr(), dx_out.stride(0), *self._bnstats_args(fuse_prev), N, h, w, st.cin, st.cout,
                      st.dil, self.dt, s)
                 fuse_prev.bwd_nparts = self._np.value
+            elif dx_out is not None and colsum is not None and FUSE_COLSUM:
+                call("unetdc_conv3x3_dgrad_colsum", dy.data_ptr(), dy.stride(0), st.w_dgrad.data_ptr(), dx_out.data_ptr(),
+                     dx_out.stride(0), colsum[0].data_ptr(), colsum[1], colsum[2], ws, wsb, N, h, w, st.cin, st.cout,
+                     st.dil, self.dt, s)
             elif dx_out is not None:
                 call("unetdc_conv3x3_dgrad", dy.data_ptr(), dy.stride(0), st.w_dgrad.data_ptr(), dx_out.data_ptr(),
                      dx_out.stride(0), N, h, w, st.cin, st.cout, st.dil, self.dt, s)
 
-    def _block_bwd(self, name, flat, lvl, dskip, dpool, dx_out):
+    def _block_bwd(self, name, flat, lvl, dskip, dpool, dx_out, colsum=None):
         """stage 3 then stage 0 of a block; the gradient between them lives in the 'da' buffer."""
         da = self.grad_bufs[("da", lvl)]
         self._stage_bwd(self.stages[(name, 3)], flat, lvl, dskip, dpool, da, fuse_prev=self.stages[(name, 0)])
-        self._stage_bwd(self.stages[(name, 0)], flat, lvl, da, None, dx_out)
+        self._stage_bwd(self.stages[(name, 0)], flat, lvl, da, None, dx_out, colsum=colsum)
         self._notify(flat, name)
 
     def _notify(self, flat, name):
@@ -436,15 +445,17 @@ class UNetEngine:
             u = self.up[lvl]
             c = u["cout"]
             dcat = g[("dcat", lvl)]
-            self._block_bwd(f"dec{lvl}", flat, l, dact, None, dcat)
+            # the dgrad that writes dcat = grad of cat([up, enc]) also sums its first half per channel = upconv bias grad
+            self._block_bwd(f"dec{lvl}", flat, l, dact, None, dcat, colsum=(self._gview(flat, u["mod"].bias), 0, c))
             dup = dcat[:, :c]
             h, w = self.res[lvl]
             xin = u["x_in"]
             with self._side_after_main() as (s2, ws2):
                 call("unetdc_convT2x2_wgrad", xin.data_ptr(), xin.stride(0), dup.data_ptr(), dup.stride(0),
                      self._gview(flat, u["mod"].weight).data_ptr(), ws2, wsb, N, h, w, u["cin"], c, self.dt, s2)
-                call("unetdc_channel_sum", dup.data_ptr(), dup.stride(0), self._gview(flat, u["mod"].bias).data_ptr(),
-                     ws2, wsb, self.npix[l], c, self.dt, s2)
+                if not FUSE_COLSUM:
+                    call("unetdc_channel_sum", dup.data_ptr(), dup.stride(0), self._gview(flat, u["mod"].bias).data_ptr(),
+                         ws2, wsb, self.npix[l], c, self.dt, s2)
             dnext = g[("da", lvl)]               # gradient w.r.t. the up-conv input (level lvl+1 resolution)
             prev = self.stages[("bottleneck" if lvl == 4 else f"dec{lvl + 1}", 3)]     # producer of the up-conv input
             if FUSE_BN_BWD:
