@@ -198,17 +198,26 @@ __global__ __launch_bounds__(512, 2) void igemm_dma_kernel(const IgemmParams p) 
     __syncthreads();                                       // ... everyone's; and stage (s+1)&1 is free
     if (s + 1 < nsteps) issue((s + 1) & 1);
     const unsigned char* base = smem + (s & 1) * STAGE;
+    // fragments of 16-channel group g+1 are read while the MFMAs of group g run (double-buffered registers,
+    // order pinned with sched_barrier): left alone, the compiler reads each fragment right before its first
+    // MFMA and every group of 2-4 MFMAs then waits out the LDS latency
+    u32x4 fa[2][TM], fb[2][2];
+    auto load_g = [&](int buf, int g) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[buf][j] = ld16(base + b_rd[g] + j * 32 * 128);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[buf][i] = ld16(base + a_rd[g] + i * 32 * 128);
+    };
+    load_g(0, 0);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      u32x4 a[TM], b[2];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = ld16(base + a_rd[g] + i * 32 * 128);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = ld16(base + b_rd[g] + j * 32 * 128);
+      if (g + 1 < 4) load_g((g + 1) & 1, g + 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) MmaD<T>::run(acc[i][j], a[i], b[j]);
+        for (int j = 0; j < 2; ++j) MmaD<T>::run(acc[i][j], fa[g & 1][i], fb[g & 1][j]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 

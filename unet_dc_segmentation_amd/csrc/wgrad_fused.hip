@@ -13,6 +13,7 @@
 // Fragments as in wgrad_frag.h: bf16 via ds_read_b64_tr_b16 on the [pixel][channel] image (64-byte
 // units XOR-swizzled by pixel row), fp32 via scalar reads.  Strips x y-ranges give the K split;
 // partial slabs are reduced by wgrad_reduce_kernel (deterministic).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "kernels.h"
@@ -168,6 +169,209 @@ __global__ __launch_bounds__(256, 2) void wgrad_fused_kernel(const WgradFusedPar
 }
 
 // ------------------------------------------------------------------------------------------------
+// Ring variant for d <= 2 (every decoder level, enc1, enc2: most of the weight-gradient time).
+//
+// SQ counters of the kernel above on enc1 (64->64, 512x512): MFMA pipe busy 40 %; a step lasts ~4.8K cycles of
+// which the two resident waves of a SIMD keep the MFMA pipe busy 2.3K -- the rest is the LDS-DMA of the NEXT
+// step (issued one step ahead, 38 KB) not having landed.  But consecutive image rows share their X rows:
+// rows y-d, y, y+d of step s are rows y+1-2d.. of later steps, so the three X segments live in a RING of
+// R = 2d + PF + 1 row slots and a step only fetches ONE new X row plus the dY row (18 KB instead of 38 KB),
+// PF steps ahead (PF = 2 when the ring fits 80 KB so that two workgroups still share a CU).
+//   group k (the loads of step k) = dY row ybeg+k -> dY slot k % (PF+1);  X row ybeg+k+d -> X slot (k+2d) % R
+//   step s: wait for group s (counted vmcnt: the younger group may stay in flight) ; barrier (everyone's
+//   group s has landed AND everyone is done with step s-1, whose oldest X row / dY slot are now free) ;
+//   issue group s+PF into exactly those slots ; 36 MFMAs per wave.
+template <typename T, int PF>
+__global__ __launch_bounds__(256, 2) void wgrad_ring_kernel(const WgradFusedParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int SEG = FusedCfg<T>::SEG;
+  constexpr int XR = SEG + 16;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int RB = 64 * ES;
+  constexpr int CPR = RB / 16, RPI = 64 / CPR;
+  constexpr int DYI = SEG / RPI, XI = XR / RPI;
+  constexpr int GI = DYI + XI;                         // DMA instructions of one group (whole workgroup)
+  constexpr int NQ = (GI + 3) / 4;                     // slots per wave
+  constexpr int DYB = SEG * RB, XB = XR * RB;
+  constexpr int NDY = PF + 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const xring = smem + NDY * DYB;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qi = wave >> 1, qj = wave & 1;
+  const int d = p.d, R = 2 * d + PF + 1;
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles = p.itiles * p.jtiles;
+  const int unit = L / tiles, trem = L - unit * tiles;
+  const int it = trem / p.jtiles, jt = trem - it * p.jtiles;
+  const int i0 = it * 64, j0 = jt * 64;
+  const int segs = p.W / SEG;
+  const int ys = unit % p.ysplit, strip = unit / p.ysplit;
+  const int n = strip / segs, x0 = (strip - n * segs) * SEG;
+  const int ybeg = ys * p.rows_per_unit;
+  const int yend = min(ybeg + p.rows_per_unit, p.H);
+  const int nsteps = yend - ybeg;
+
+  const unsigned dybytes = (unsigned)((long)p.N * p.H * p.W * p.lddy * ES);
+  const unsigned xbytes = (unsigned)((long)p.N * p.H * p.W * p.ldx * ES);
+  const __amdgpu_buffer_rsrc_t dyr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, dybytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, xbytes, 0x00020000);
+
+  // DMA slot q of this wave -> instruction gi = wave + 4q of a group: gi < DYI: dY row; else X row instruction gi - DYI
+  const int sub = lane / CPR, pc = lane % CPR;
+  unsigned colb[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int gi = wave + 4 * q;
+    if (gi < DYI) {
+      const int row = gi * RPI + sub;
+      colb[q] = (unsigned)(((x0 + row) * p.lddy + i0) * ES + Frag<T, 1>::src_chunk(row, pc) * 16);
+    } else if (gi < GI) {
+      const int row = (gi - DYI) * RPI + sub;
+      const int gx = x0 - d + row;
+      colb[q] = ((unsigned)gx < (unsigned)p.W) ? (unsigned)((gx * p.ldx + j0) * ES + Frag<T, 1>::src_chunk(row, pc) * 16) : FOOB;
+    } else {
+      colb[q] = FOOB;
+    }
+  }
+  const bool five = (wave + 4 * (NQ - 1)) < GI;          // does this wave's last slot exist? (wave-uniform)
+
+  // X row `yy` of the image -> ring slot `slot` (zeros when the row lies outside the image)
+  auto issue_x = [&](int slot, int yy) {
+    const bool yok = (unsigned)yy < (unsigned)p.H;
+    const unsigned rowbase = (unsigned)((long)(n * p.H + (yok ? yy : 0)) * p.W * p.ldx * ES);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int gi = wave + 4 * q;
+      if (gi >= DYI && gi < GI) {
+        const unsigned v = (yok && colb[q] != FOOB) ? rowbase + colb[q] : FOOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, LDS_PTR(xring + slot * XB + (gi - DYI) * 1024), 16, v, 0, 0, 0);
+      }
+    }
+  };
+  auto issue_dy = [&](int slot, int y) {
+    const unsigned rowbase = (unsigned)((long)(n * p.H + y) * p.W * p.lddy * ES);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int gi = wave + 4 * q;
+      if (gi < DYI)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(dyr, LDS_PTR(smem + slot * DYB + gi * 1024), 16, rowbase + colb[q], 0, 0, 0);
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  // prologue: X rows ybeg-d .. ybeg+d-1 (ring rows 0 .. 2d-1), then groups 0 .. PF-1
+  for (int rho = 0; rho < 2 * d; ++rho) issue_x(rho, ybeg - d + rho);
+  int gslot_x = 2 * d, gslot_dy = 0;                     // slots of the next group to issue
+#pragma unroll
+  for (int k = 0; k < PF; ++k) {
+    if (k < nsteps) {
+      issue_dy(gslot_dy, ybeg + k);
+      issue_x(gslot_x, ybeg + k + d);
+      gslot_dy = (gslot_dy + 1 == NDY) ? 0 : gslot_dy + 1;
+      gslot_x = (gslot_x + 1 == R) ? 0 : gslot_x + 1;
+    }
+  }
+  int sl0 = 0, sl1 = d, sl2 = 2 * d, sdy = 0;            // ring slots of rows y-d, y, y+d and the dY slot of step s
+  for (int s = 0; s < nsteps; ++s) {
+    if (PF == 2 && s + 1 < nsteps) {                     // the group of step s+1 may stay in flight
+      if (five) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ - 1) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (s + PF < nsteps) {
+      issue_dy(gslot_dy, ybeg + s + PF);
+      issue_x(gslot_x, ybeg + s + PF + d);
+      gslot_dy = (gslot_dy + 1 == NDY) ? 0 : gslot_dy + 1;
+      gslot_x = (gslot_x + 1 == R) ? 0 : gslot_x + 1;
+    }
+    const unsigned char* sdyp = smem + sdy * DYB;
+    const unsigned char* sx[3] = {xring + sl0 * XB, xring + sl1 * XB, xring + sl2 * XB};
+    if constexpr (sizeof(T) == 2) {
+      // Fragment reads two groups ahead of the MFMAs that consume them (group = one k16 x one X row = 3 taps).
+      // Left to itself the compiler reads each fragment one MFMA before its use, and every MFMA then waits out the
+      // LDS latency: 36 x ~130 cycles per step instead of 36 x 32.
+      constexpr int NG = (SEG / 16) * 3;
+      bf16x8 fa[2], fb[3][3];
+      auto load_group = [&](int g) {
+        const int k16 = g / 3, ky = g - k16 * 3;
+        if (ky == 0) fa[k16 & 1] = Frag<bf16_t, 1>::frag(sdyp, lane, qi * 32, 16 * k16);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) fb[g % 3][kx] = Frag<bf16_t, 1>::frag(sx[ky], lane, qj * 32, 16 * k16 + kx * d);
+      };
+      load_group(0);
+      load_group(1);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (g + 2 < NG) load_group(g + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        const int k16 = g / 3, ky = g - k16 * 3;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+          acc[3 * ky + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[k16 & 1], fb[g % 3][kx], acc[3 * ky + kx], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int k16 = 0; k16 < SEG / 16; ++k16) {
+      if constexpr (sizeof(T) == 2) {
+      } else {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int kp = 0; kp < 8; ++kp) {
+          const int krow = 16 * k16 + 2 * kp + h;
+          const float fa = *reinterpret_cast<const float*>(sdyp + krow * RB + (qi * 32 + r) * 4);
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t - ky * 3;
+            const float fb = *reinterpret_cast<const float*>(sx[ky] + (krow + kx * d) * RB + (qj * 32 + r) * 4);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+    sl0 = (sl0 + 1 == R) ? 0 : sl0 + 1;
+    sl1 = (sl1 + 1 == R) ? 0 : sl1 + 1;
+    sl2 = (sl2 + 1 == R) ? 0 : sl2 + 1;
+    sdy = (sdy + 1 == NDY) ? 0 : sdy + 1;
+  }
+
+  // ---- partial slab: part[unit][t][i][j] ---------------------------------------------------------
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float* slab = p.part + ((long)unit * 9 + t) * p.CI * p.CJ + (long)(i0 + qi * 32 + 4 * h) * p.CJ + j0 + qj * 32 + r;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) slab[(long)((reg & 3) + 8 * (reg >> 2)) * p.CJ] = acc[t][reg];
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+// LDS bytes of the ring kernel, or 0 when the configuration does not leave room for two workgroups per CU
+static int ring_lds(int d, int dtype, int pf) {
+  const int es = dtype == UNETDC_BF16 ? 2 : 4, seg = dtype == UNETDC_BF16 ? 64 : 32;
+  const int dyb = seg * 64 * es, xb = (seg + 16) * 64 * es;
+  const int lds = (pf + 1) * dyb + (2 * d + pf + 1) * xb;
+  return lds <= 80 * 1024 ? lds : 0;
+}
+static int ring_pf(int d, int dtype) {
+  static int off = -1;                                   // UNETDC_WGRAD_RING=0: always the three-segment kernel (A/B)
+  if (off < 0) { const char* e = getenv("UNETDC_WGRAD_RING"); off = (e && e[0] == '0') ? 1 : 0; }
+  if (off || d > 2) return 0;
+  if (ring_lds(d, dtype, 2)) return 2;
+  if (ring_lds(d, dtype, 1)) return 1;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 static int fused_seg(int dtype) { return dtype == UNETDC_BF16 ? 64 : 32; }
 
 bool wgrad_fused_supported(int N, int H, int W, int CI, int CJ, int lda, int ldb, int d, int ntaps, int stride,
@@ -224,6 +428,35 @@ int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* 
   const int units = N * (W / fused_seg(dtype)) * p.ysplit;
   *units_out = units;
   const long nwg = (long)units * p.itiles * p.jtiles;
+  const int pf = ring_pf(d, dtype);
+  if (pf) {
+    const int lds = ring_lds(d, dtype, pf);
+    const void* fn;
+    if (dtype == UNETDC_BF16) fn = pf == 2 ? reinterpret_cast<const void*>(&wgrad_ring_kernel<bf16_t, 2>)
+                                            : reinterpret_cast<const void*>(&wgrad_ring_kernel<bf16_t, 1>);
+    else fn = pf == 2 ? reinterpret_cast<const void*>(&wgrad_ring_kernel<float, 2>)
+                      : reinterpret_cast<const void*>(&wgrad_ring_kernel<float, 1>);
+    static bool ring_attr[2][3] = {{false, false, false}, {false, false, false}};
+    if (!ring_attr[dtype][pf]) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(wgrad_ring_kernel) failed: %s", hipGetErrorString(e));
+        return UNETDC_ELAUNCH;
+      }
+      ring_attr[dtype][pf] = true;
+    }
+    if (dtype == UNETDC_BF16) {
+      if (pf == 2) hipLaunchKernelGGL((wgrad_ring_kernel<bf16_t, 2>), dim3((unsigned)nwg), dim3(256), lds, stream, p);
+      else hipLaunchKernelGGL((wgrad_ring_kernel<bf16_t, 1>), dim3((unsigned)nwg), dim3(256), lds, stream, p);
+    } else {
+      if (pf == 2) hipLaunchKernelGGL((wgrad_ring_kernel<float, 2>), dim3((unsigned)nwg), dim3(256), lds, stream, p);
+      else hipLaunchKernelGGL((wgrad_ring_kernel<float, 1>), dim3((unsigned)nwg), dim3(256), lds, stream, p);
+    }
+    char nm[64];
+    snprintf(nm, sizeof(nm), "wgrad_ring_kernel<%s, %d>", dtype == UNETDC_BF16 ? "__bf16" : "float", pf);
+    note_kernel(nm);
+    return check_launch("wgrad_ring_kernel");
+  }
   const int es = dtype == UNETDC_BF16 ? 2 : 4;
   const int seg = fused_seg(dtype);
   const int lds = 2 * (seg * 64 * es + 3 * (seg + 16) * 64 * es);
