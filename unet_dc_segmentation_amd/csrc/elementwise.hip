@@ -385,13 +385,16 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadParams p) {
   }
 }
 
-__global__ void head_bwd_finalize_kernel(const float* __restrict__ parts, int nparts, float* dw, float* db, int OC,
-                                         int C) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void head_bwd_finalize_kernel(const float* __restrict__ parts, int nparts, float* dw,
+                                                                float* db, int OC, int C) {
+  // 32 lanes per output element, rows l, l+32, ... each, fixed shuffle tree
+  const int i = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
   const int L = OC * (C + 1);
-  if (i >= L) return;
   double s = 0.0;
-  for (int q = 0; q < nparts; ++q) s += (double)parts[(long)q * L + i];
+  if (i < L)
+    for (int q = l; q < nparts; q += 32) s += (double)parts[(long)q * L + i];
+  s = lane32_sum(s);
+  if (i >= L || l != 0) return;
   const int oc = i / (C + 1), c = i - oc * (C + 1);
   if (c < C) dw[oc * C + c] = (float)s;
   else db[oc] = (float)s;
@@ -741,7 +744,7 @@ int launch_head_bwd(HeadParams& p, float* dw, float* db, void* workspace, long w
   const float* rp; int rows;
   rc = reduce_parts(p.parts, nb, L, &rp, &rows, stream);
   if (rc != UNETDC_OK) return rc;
-  hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3((L + 63) / 64), dim3(64), 0, stream, rp, rows, dw, db, p.OC, p.C);
+  hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3((L + 7) / 8), dim3(256), 0, stream, rp, rows, dw, db, p.OC, p.C);
   return check_launch("head_bwd_finalize_kernel");
 }
 

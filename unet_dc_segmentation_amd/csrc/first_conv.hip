@@ -158,15 +158,21 @@ __global__ __launch_bounds__(256) void first_conv_wgrad_kernel(const FirstWgradP
 }
 
 // dw[co][ci][t] = sum_blk part[blk][ci][t][co]
-__global__ void first_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nblk, int Cin,
-                                          int Cout) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// 32 lanes per output: lane l adds blocks l, l+32, ... in order, then a fixed shuffle tree (deterministic).  One thread
+// per output walking all 512 block partials took 120 us -- pure load latency on three workgroups.
+__global__ __launch_bounds__(256) void first_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                 int nblk, int Cin, int Cout) {
   const int n = Cin * 9 * Cout;
-  if (i >= n) return;
-  const int co = i % Cout, k = i / Cout;        // k = ci*9 + t
+  const int i = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += part[(long)b * n + i];
-  dw[(long)co * Cin * 9 + k] = s;
+  if (i < n)
+    for (int b = l; b < nblk; b += 32) s += part[(long)b * n + i];
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 32);
+  if (i < n && l == 0) {
+    const int co = i % Cout, k = i / Cout;      // k = ci*9 + t
+    dw[(long)co * Cin * 9 + k] = s;
+  }
 }
 
 static int first_blocks(long P, int Cout) {
@@ -224,7 +230,7 @@ int launch_first_wgrad(FirstWgradParams& p, float* dw, void* workspace, long wor
   int rc = check_launch("first_conv_wgrad_kernel");
   if (rc != UNETDC_OK) return rc;
   const int n = p.Cin * 9 * p.Cout;
-  hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p.part, dw, (int)nb,
+  hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3((n + 7) / 8), dim3(256), 0, stream, p.part, dw, (int)nb,
                      p.Cin, p.Cout);
   return check_launch("first_wgrad_reduce_kernel");
 }

@@ -53,29 +53,38 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restric
 }
 
 // one block: out[0] = loss; coef[img] = {2/(U+s), (2I+s)/(U+s)^2}
+// 32 lanes share an image: lane l adds block partials l, l+32, ... (fp64), then a fixed shuffle tree.
+__device__ __forceinline__ double loss_lane32_sum(double v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
+  return v;
+}
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ parts, int nimg, int nblk,
                                                             double numel, float ratio, float smooth, float* out,
                                                             float* coef) {
-  __shared__ double sh_focal[256], sh_dice[256];
+  __shared__ double sh_focal[8], sh_dice[8];
+  const int grp = threadIdx.x >> 5, l = threadIdx.x & 31;
   double focal = 0.0, dice = 0.0;
-  for (int img = threadIdx.x; img < nimg; img += 256) {
+  for (int img = grp; img < nimg; img += 8) {
     double f = 0.0, I = 0.0, P = 0.0, T = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = l; b < nblk; b += 32) {
       const float* q = parts + ((long)img * nblk + b) * 4;
       f += q[0]; I += q[1]; P += q[2]; T += q[3];
     }
+    f = loss_lane32_sum(f); I = loss_lane32_sum(I); P = loss_lane32_sum(P); T = loss_lane32_sum(T);
     const double U = P + T + (double)smooth;
     focal += f;
     dice += (2.0 * I + (double)smooth) / U;
-    coef[img * 2 + 0] = (float)(2.0 / U);
-    coef[img * 2 + 1] = (float)((2.0 * I + (double)smooth) / (U * U));
+    if (l == 0) {
+      coef[img * 2 + 0] = (float)(2.0 / U);
+      coef[img * 2 + 1] = (float)((2.0 * I + (double)smooth) / (U * U));
+    }
   }
-  sh_focal[threadIdx.x] = focal;
-  sh_dice[threadIdx.x] = dice;
+  if (l == 0) { sh_focal[grp] = focal; sh_dice[grp] = dice; }
   __syncthreads();
   if (threadIdx.x == 0) {
     double f = 0.0, d = 0.0;
-    for (int i = 0; i < 256; ++i) { f += sh_focal[i]; d += sh_dice[i]; }
+    for (int i = 0; i < 8; ++i) { f += sh_focal[i]; d += sh_dice[i]; }
     out[0] = (float)((double)ratio * (f / numel) + (1.0 - (double)ratio) * (1.0 - d / nimg));
   }
 }

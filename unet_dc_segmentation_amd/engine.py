@@ -255,7 +255,7 @@ class UNetEngine:
                  _ptr(bn.running_var) if track else None, st.scale.data_ptr(), st.shift.data_ptr(),
                  st.mean.data_ptr(), st.rstd.data_ptr(), st.cout, s)
             if track:
-                bn.num_batches_tracked += 1
+                self._nbt.append(bn.num_batches_tracked)       # incremented together at the end of forward()
             call("unetdc_bn_relu_apply", y.data_ptr(), y.stride(0), st.scale.data_ptr(), st.shift.data_ptr(),
                  dst.data_ptr(), dst.stride(0), _ptr(pooled), pooled.stride(0) if pooled is not None else 0,
                  N, h, w, st.cout, self.dt, s)
@@ -277,6 +277,7 @@ class UNetEngine:
 
     def forward(self, x, train):
         self._pack(need_dgrad=train)
+        self._nbt = []
         s = _stream()
         N = self.N
         widths = [64, 128, 256, 512, 1024]
@@ -307,6 +308,8 @@ class UNetEngine:
         call("unetdc_head_fwd", hin.data_ptr(), hin.stride(0), oc.weight.data_ptr(), oc.bias.data_ptr(),
              probs.data_ptr(), N, self.H, self.W, 64, self.oc, self.dt, s)
         self.head_in = hin
+        if self._nbt:
+            torch._foreach_add_(self._nbt, 1)                  # nn.BatchNorm2d's num_batches_tracked += 1, one launch
         return probs
 
     # ------------------------------------------------------------------ backward
