@@ -90,7 +90,7 @@ int unetdc_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float
 
 /* ---- first encoder convolution (small Cin, reads the NCHW fp32 image): model_2.py:10 (enc1.0) ---
  * w is the fp32 PyTorch-layout parameter itself.  Same scale/shift/stats semantics as above. */
-int unetdc_conv3x3_first_stats_rows(int64_t npixels, int cout);
+int unetdc_conv3x3_first_stats_rows(int64_t npixels, int cin, int cout);
 int unetdc_conv3x3_first_fwd(const float* x_nchw, const float* w, const float* bias, const float* scale,
                              const float* shift, void* y, int ldy, float* stats_part, int n, int h, int wd, int cin,
                              int cout, int dilation, int dtype, unetdc_stream_t s);

@@ -117,8 +117,12 @@ def test_wgrad_many_pixels_ksplit(dtype):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("cin", [1, 3])
-def test_first_conv(dtype, cin):
-    n, h, w, cout, d = 2, 24, 40, 64, 1
+@pytest.mark.parametrize("shape", [(2, 24, 40, 1), (2, 64, 64, 2), (3, 10, 10, 1)])
+def test_first_conv(dtype, cin, shape):
+    """(2,24,40): fp32-MFMA kernels, division path; (2,64,64) d=2: shift path, several workgroups;
+    (3,10,10): pixel count not a multiple of 32 -> VALU kernels of first_conv.hip."""
+    n, h, w, d = shape
+    cout = 64
     g = gen(5)
     x = torch.rand(n, cin, h, w, generator=g)
     wt = torch.randn(cout, cin, 3, 3, generator=g) / 3
@@ -128,7 +132,7 @@ def test_first_conv(dtype, cin):
     y_ref = F.conv2d(x, wr, b, padding=d, dilation=d)
     gw_ref, = torch.autograd.grad(y_ref, wr, dy)
     xd, wdv, bd = x.cuda(), wt.cuda(), b.cuda()
-    rows = _lib.load().unetdc_conv3x3_first_stats_rows(n * h * w, cout)
+    rows = _lib.load().unetdc_conv3x3_first_stats_rows(n * h * w, cin, cout)
     st = torch.full(((rows + 64) * 2 * cout,), float("nan"), device="cuda")
     yv = G.empty_nhwc(n * h * w, cout, dtype)
     call("unetdc_conv3x3_first_fwd", xd.data_ptr(), wdv.data_ptr(), bd.data_ptr(), None, None, yv.data_ptr(),
@@ -144,7 +148,7 @@ def test_first_conv(dtype, cin):
     y2v = G.empty_nhwc(n * h * w, cout, dtype)
     call("unetdc_conv3x3_first_fwd", xd.data_ptr(), wdv.data_ptr(), None, scd.data_ptr(), shd.data_ptr(),
          y2v.data_ptr(), y2v.stride(0), None, n, h, w, cin, cout, d, G.DT[dtype], G.stream())
-    y2_ref = torch.relu(F.conv2d(x, wt, None, padding=d) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    y2_ref = torch.relu(F.conv2d(x, wt, None, padding=d, dilation=d) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
     assert rel(G.from_nhwc(y2v, n, h, w), y2_ref) < (2e-6 if dtype == "f32" else 4e-3)
     # wgrad
     nbytes = _lib.load().unetdc_conv3x3_first_wgrad_workspace(n, h, w, cin, cout)

@@ -193,7 +193,9 @@ int unetdc_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float
   return launch_wgrad(p, dw, workspace, (long)workspace_bytes, dtype, (hipStream_t)s);
 }
 
-int unetdc_conv3x3_first_stats_rows(int64_t npixels, int cout) { return first_conv_mblocks((long)npixels, cout); }
+int unetdc_conv3x3_first_stats_rows(int64_t npixels, int cin, int cout) {
+  return first_conv_mblocks((long)npixels, cin, cout);
+}
 
 int unetdc_conv3x3_first_fwd(const float* x_nchw, const float* w, const float* bias, const float* scale,
                              const float* shift, void* y, int ldy, float* stats_part, int n, int h, int wd, int cin,

@@ -64,7 +64,12 @@ struct FirstWgradParams {
   int N, H, W, Cin, Cout, lddy, dil;
 };
 int launch_first_fwd(FirstParams& p, int dtype, hipStream_t stream);
-int first_conv_mblocks(long P, int Cout);
+int first_conv_mblocks(long P, int Cin, int Cout);
+bool first_mfma_supported(long P, int Cin, int Cout);
+int first_mfma_mblocks(long P);
+int launch_first_mfma_fwd(FirstParams& p, int dtype, hipStream_t stream);
+long first_mfma_wgrad_workspace_bytes(long P, int Cin, int Cout);
+int launch_first_mfma_wgrad(FirstWgradParams& p, int* nblk_out, int dtype, hipStream_t stream);
 long first_wgrad_workspace_bytes(long P, int Cin, int Cout);
 int launch_first_wgrad(FirstWgradParams& p, float* dw, void* workspace, long workspace_bytes, int dtype,
                        hipStream_t stream);

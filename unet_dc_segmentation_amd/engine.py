@@ -61,7 +61,7 @@ class _Stage:
         f32 = dict(device=dev, dtype=torch.float32)
         self.y = torch.empty(npix, cout, device=dev, dtype=dt)          # raw conv output (pre-BN)
         if first:
-            rows = _lib.load().unetdc_conv3x3_first_stats_rows(npix, cout)
+            rows = _lib.load().unetdc_conv3x3_first_stats_rows(npix, cin, cout)
         else:
             rows = _lib.load().unetdc_conv3x3_stats_rows(npix, cout)
             self.w_fwd = torch.empty(9 * cout * cin, device=dev, dtype=dt)
