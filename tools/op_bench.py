@@ -15,9 +15,14 @@ op, n, h, w, cin, cout, d = sys.argv[1], *map(int, sys.argv[2:8])
 dtype = sys.argv[8] if len(sys.argv) > 8 else "bf16"
 reps = int(sys.argv[9]) if len(sys.argv) > 9 else 20
 g = torch.Generator().manual_seed(0)
+ZERO = os.environ.get("ZERO") == "1"          # all-zero operands: same instruction stream, far less switching power
 x = torch.randn(n * h * w, cin, generator=g).to(G.TD[dtype]).cuda()
 dy = torch.randn(n * h * w, cout, generator=g).to(G.TD[dtype]).cuda()
+if ZERO:
+    x.zero_(); dy.zero_()
 wt = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5))
+if ZERO:
+    wt.zero_()
 wf, wd = G.pack_conv(wt, dtype)
 y = torch.empty(n * h * w, cout, dtype=G.TD[dtype], device="cuda")
 dx = torch.empty(n * h * w, cin, dtype=G.TD[dtype], device="cuda")

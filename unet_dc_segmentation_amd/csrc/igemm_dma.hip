@@ -186,9 +186,14 @@ __global__ __launch_bounds__(512, 2) void igemm_dma_kernel(const IgemmParams p) 
     for (int j = 0; j < BI; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, LDS_PTR(sbase + BM * 128 + (wave + NW * j) * 1024), 16,
                                                bbase[j] + wbytes_t, 0, 0, 0);
-    if (++lkc == nkc) {
-      lkc = 0;
-      do { ++lt; } while (lt < p.ntaps && !((tapmask >> lt) & 1u));
+    // K order: 64-channel chunk OUTER, tap INNER.  The nine taps of one chunk re-read (shifted) the same 32 KB of
+    // input, back to back, so they hit in the XCD's 4 MB L2; with the tap outer a workgroup streamed its whole
+    // 256-pixel x Cin slab between two uses and every tap came from beyond L2 (PMC: 2.1x the algorithmic bytes).
+    do { ++lt; } while (lt < p.ntaps && !((tapmask >> lt) & 1u));
+    if (lt >= p.ntaps) {
+      ++lkc;
+      lt = 0;
+      while (lt < p.ntaps && !((tapmask >> lt) & 1u)) ++lt;
     }
   };
 
@@ -372,6 +377,10 @@ int launch_igemm_dma(IgemmParams& p, int dtype, hipStream_t stream) {
   const long blocks_a = (long)((p.M + 255) / 256) * (p.Cout / 256);
   const bool use_a = (force == 1) || (force == 0 && p.Cout % 256 == 0 && p.M >= 256 * 64 && blocks_a >= 200);
   const bool use_b = (force == 2) || (force == 0 && !use_a && p.Cout % 128 == 0);
+  if (igemm_dma16_supported(p, dtype)) {               // bf16: 16x16x32 MFMA shape (igemm_dma16.hip)
+    const int cfg = (use_a && p.Cout % 256 == 0) ? 1 : ((use_b && p.Cout % 128 == 0) ? 2 : 3);
+    return launch_igemm_dma16(p, cfg, stream);
+  }
   if (use_a && p.Cout % 256 == 0) {
     return dtype == UNETDC_BF16 ? launch_dma_cfg<bf16_t, 2, 4, 4>(p, stream) : launch_dma_cfg<float, 2, 4, 4>(p, stream);
   }

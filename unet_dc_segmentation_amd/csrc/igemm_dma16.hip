@@ -1,0 +1,385 @@
+// bf16 implicit-GEMM convolution with LDS-DMA staging on the 16x16x32 MFMA shape.
+//
+// Same tiles, same LDS image, same pipeline as igemm_dma.hip (read that file first); what changes is the matrix
+// instruction: v_mfma_f32_16x16x32_bf16 instead of v_mfma_f32_32x32x16_bf16.  Why: the kernels are POWER bound,
+// not issue bound -- with all-zero operands the identical instruction stream runs 27-33 % faster (1.02 -> 1.33
+// PFLOP/s on 512->512, 1.24 -> 1.65 on the bottleneck layer; tools/op_bench.py ZERO=1), i.e. the chip lowers its
+// clock under the switching activity of real data.  MI355X_MICROARCH.md (DVFS, item 7) measures ~1.12-1.15x the
+// FLOP/s for the 16x16x32 shape at equal cycles per FLOP with operands re-read from LDS.  LDS traffic per FLOP is
+// unchanged: a wave still owns a (TM*16) x 64 output tile and reads TM + 4 fragments per 32-channel group.
+//
+// Layouts (lane l, c = l & 15, rb = l >> 4):
+//   A / B fragment : row (or output channel row) c of the 16-row tile, K elements 8*rb .. 8*rb+7 of the 32-group
+//                    = 16-byte chunk 4*g + rb of the 128-byte LDS row (XOR-swizzled with (row>>1)&7 like before;
+//                    the four 16-lane groups of a ds_read_b128 still land on 16 distinct bank quads);
+//   accumulator    : acc[i][j][v] = out[pixel 16*i + 4*rb + v][channel 4*c + j]: the B rows are ordered so that
+//                    the FOUR N tiles of a wave hold the four consecutive channels 4c..4c+3 -- a lane packs them
+//                    into one 8-byte store and 16 lanes write one whole 128-byte pixel row.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "igemm_epilogue.h"
+#include "kernels.h"
+
+namespace unetdc {
+
+#define LDS_PTR16(p) ((__attribute__((address_space(3))) void*)(p))
+constexpr unsigned OOB16 = 0x80000000u;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ u32x2 pack4_bf16(float a, float b, float c, float d) {
+  u32x2 r;
+  r[0] = OutPair<bf16_t>::pack(a, b);
+  r[1] = OutPair<bf16_t>::pack(c, d);
+  return r;
+}
+__device__ __forceinline__ void unpack4_bf16(const u32x2& r, float (&t)[4]) {
+  const unsigned int u0 = r[0], u1 = r[1];
+  t[0] = bits_f32(u0 << 16); t[1] = bits_f32(u0 & 0xffff0000u);
+  t[2] = bits_f32(u1 << 16); t[3] = bits_f32(u1 & 0xffff0000u);
+}
+
+// TMT M-tiles of 16 rows x 4 N-tiles of 16 channels per wave -> global memory (bf16)
+template <int MODE, int TMT>
+__device__ __forceinline__ void epilogue16(const IgemmParams& p, f32x4 (&acc)[TMT][4], const bool (&tile_ok)[TMT],
+                                           const unsigned (&voff)[TMT], unsigned row_bytes, const unsigned (&yoff)[TMT],
+                                           unsigned yrow_bytes, int ccol, float (&s)[4], float (&q)[4]) {
+  const __amdgpu_buffer_rsrc_t orr = whole_buffer(p.out);
+  const __amdgpu_buffer_rsrc_t yrr = whole_buffer(MODE == MODE_BNBWD ? p.bn_y : p.out);
+  float k0[4] = {0.f, 0.f, 0.f, 0.f}, k1[4] = {0.f, 0.f, 0.f, 0.f}, mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f};
+  if (MODE == MODE_AFFINE_RELU || MODE == MODE_BNBWD) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { k0[k] = p.scale[ccol + k]; k1[k] = p.shift[ccol + k]; }
+  } else if (p.bias) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) k1[k] = p.bias[ccol + k];
+  }
+  if (MODE == MODE_BNBWD) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { mu[k] = p.bn_mean[ccol + k]; rs[k] = p.bn_rstd[ccol + k]; }
+  }
+  constexpr int GRP = TMT < 4 ? TMT : 4;                  // tiles whose saved-output loads are in flight together
+#pragma unroll
+  for (int i0 = 0; i0 < TMT; i0 += GRP) {
+    u32x2 yraw[GRP][4];
+    if (MODE == MODE_BNBWD) {
+#pragma unroll
+      for (int ii = 0; ii < GRP; ++ii)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          yraw[ii][v] = tile_ok[i0 + ii] ? __builtin_amdgcn_raw_buffer_load_b64(yrr, yoff[i0 + ii], (unsigned)v * yrow_bytes, 0)
+                                         : u32x2{0u, 0u};
+    }
+#pragma unroll
+    for (int ii = 0; ii < GRP; ++ii) {
+      const int i = i0 + ii;
+      if (!tile_ok[i]) continue;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        float x[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = acc[i][k][v];
+        if (MODE == MODE_AFFINE_RELU) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) x[k] = fmaxf(fmaf(x[k], k0[k], k1[k]), 0.f);
+        } else if (MODE != MODE_BNBWD) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) x[k] += k1[k];
+        }
+        const u32x2 pk = pack4_bf16(x[0], x[1], x[2], x[3]);
+        __builtin_amdgcn_raw_buffer_store_b64(pk, orr, voff[i], (unsigned)v * row_bytes, 0);
+        if (MODE == MODE_STATS) {
+          float t[4];
+          unpack4_bf16(pk, t);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { s[k] += t[k]; q[k] = fmaf(t[k], t[k], q[k]); }
+        } else if (MODE == MODE_BNBWD) {
+          float t[4], y[4];
+          unpack4_bf16(pk, t);
+          unpack4_bf16(yraw[ii][v], y);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float g = fmaf(y[k], k0[k], k1[k]) > 0.f ? t[k] : 0.f;
+            s[k] += g;
+            q[k] = fmaf(g, (y[k] - mu[k]) * rs[k], q[k]);
+          }
+        }
+      }
+    }
+  }
+}
+#endif
+
+// WM x WN waves; each wave owns (TMT*16) x 64 outputs (TMT x 4 MFMA 16x16 tiles).
+template <int WM, int WN, int TMT>
+__global__ __launch_bounds__(512, 2) void igemm_dma16_kernel(const IgemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NW = WM * WN;
+  constexpr int BM = WM * TMT * 16, BN = WN * 64;
+  constexpr int AI = BM / 8 / NW, BI = BN / 8 / NW;
+  constexpr int ES = 2, KE = 64;
+  constexpr int STAGE = (BM + BN) * 128;
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/wave mismatch");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int mblk = tile / p.nblocks, nblk = tile - mblk * p.nblocks;
+  const int m0 = mblk * BM, n0 = nblk * BN;
+  const int HoWo = p.Ho * p.Wo;
+
+  const unsigned xbytes = (unsigned)(((long)p.M / HoWo) * p.Hi * p.Wi * p.ldx * ES);
+  const unsigned wbytes = (unsigned)((long)p.ntaps * p.Cout * p.Cin * ES);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, wbytes, 0x00020000);
+
+  const bool p2 = p.wo_shift >= 0;
+  auto decode = [&](int m, int& n, int& oy, int& ox) {
+    if (p2) {
+      n = m >> p.howo_shift;
+      const int rem = m & (HoWo - 1);
+      oy = rem >> p.wo_shift;
+      ox = rem & (p.Wo - 1);
+    } else {
+      n = m / HoWo;
+      const int rem = m - n * HoWo;
+      oy = rem / p.Wo;
+      ox = rem - oy * p.Wo;
+    }
+  };
+  unsigned tapmask = 0;
+  {
+    int na, ya, xa, nb, yb, xb;
+    const int mlast = (m0 + BM < p.M ? m0 + BM : p.M) - 1;
+    decode(m0, na, ya, xa);
+    decode(mlast, nb, yb, xb);
+    int by0 = 0, by1 = p.Ho - 1, bx0 = 0, bx1 = p.Wo - 1;
+    if (na == nb) {
+      by0 = ya; by1 = yb;
+      if (ya == yb) { bx0 = xa; bx1 = xb; }
+    }
+    for (int t = 0; t < p.ntaps; ++t) {
+      const int iy0 = by0 * p.stride + p.offy[t], iy1 = by1 * p.stride + p.offy[t];
+      const int ix0 = bx0 * p.stride + p.offx[t], ix1 = bx1 * p.stride + p.offx[t];
+      if (iy1 >= 0 && iy0 < p.Hi && ix1 >= 0 && ix0 < p.Wi) tapmask |= 1u << t;
+    }
+    tapmask = __builtin_amdgcn_readfirstlane(tapmask);
+  }
+  const int sub = lane >> 3, pc = lane & 7;
+  int ys[AI], xs[AI];
+  unsigned abase[AI];
+#pragma unroll
+  for (int j = 0; j < AI; ++j) {
+    const int row = (wave + NW * j) * 8 + sub;
+    const int m = m0 + row;
+    const int c = pc ^ ((row >> 1) & 7);
+    if (m < p.M) {
+      int n, oy, ox;
+      decode(m, n, oy, ox);
+      ys[j] = oy * p.stride;
+      xs[j] = ox * p.stride;
+      abase[j] = (unsigned)(((n * p.Hi + ys[j]) * p.Wi + xs[j]) * p.ldx * ES + c * 16);
+    } else {
+      ys[j] = -(1 << 28);
+      xs[j] = 0;
+      abase[j] = 0;
+    }
+  }
+  // B rows: LDS row q of a 64-channel group = N tile (q >> 4), column (q & 15) holds output channel 4*(q & 15) + (q >> 4)
+  unsigned bbase[BI];
+#pragma unroll
+  for (int j = 0; j < BI; ++j) {
+    const int lrow = (wave + NW * j) * 8 + sub;
+    const int grp = lrow >> 6, q = lrow & 63;
+    const int cc = (q & 15) * 4 + (q >> 4);
+    const int c = pc ^ ((lrow >> 1) & 7);
+    bbase[j] = (unsigned)((n0 + grp * 64 + cc) * p.Cin * ES + c * 16);
+  }
+  const int nkc = p.Cin / KE;
+  const int nsteps = __popc(tapmask) * nkc;
+
+  // fragment read offsets: row c of a tile, chunk 4*g + rb (swizzle is the same for every 16-row tile)
+  const int c16 = lane & 15, rb = lane >> 4;
+  const int swz = (c16 >> 1) & 7;
+  int a_rd[2], b_rd[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int ch = ((4 * g + rb) ^ swz) << 4;
+    a_rd[g] = (wm * TMT * 16 + c16) * 128 + ch;
+    b_rd[g] = BM * 128 + (wn * 64 + c16) * 128 + ch;
+  }
+
+  f32x4 acc[TMT][4];
+#pragma unroll
+  for (int i = 0; i < TMT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+  int lt = 0, lkc = 0;
+  while (lt < p.ntaps && !((tapmask >> lt) & 1u)) ++lt;
+
+  auto issue = [&](int stage) {
+    const int dy = p.offy[lt], dx = p.offx[lt];
+    const unsigned dbytes = (unsigned)((dy * p.Wi + dx) * p.ldx * ES + lkc * 128);
+    unsigned char* sbase = smem + stage * STAGE;
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {
+      const int iy = ys[j] + dy, ix = xs[j] + dx;
+      const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      const unsigned voff = ok ? abase[j] + dbytes : OOB16;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, LDS_PTR16(sbase + (wave + NW * j) * 1024), 16, voff, 0, 0, 0);
+    }
+    const unsigned wbytes_t = (unsigned)(lt * p.Cout * p.Cin * ES + lkc * 128);
+#pragma unroll
+    for (int j = 0; j < BI; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, LDS_PTR16(sbase + BM * 128 + (wave + NW * j) * 1024), 16,
+                                               bbase[j] + wbytes_t, 0, 0, 0);
+    // K order: 64-channel chunk OUTER, tap INNER.  The nine taps of one chunk re-read (shifted) the same 32 KB of
+    // input, back to back, so they hit in the XCD's 4 MB L2; with the tap outer a workgroup streamed its whole
+    // 256-pixel x Cin slab between two uses and every tap came from beyond L2 (PMC: 2.1x the algorithmic bytes).
+    do { ++lt; } while (lt < p.ntaps && !((tapmask >> lt) & 1u));
+    if (lt >= p.ntaps) {
+      ++lkc;
+      lt = 0;
+      while (lt < p.ntaps && !((tapmask >> lt) & 1u)) ++lt;
+    }
+  };
+
+  if (nsteps > 0) issue(0);
+  for (int s = 0; s < nsteps; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (s + 1 < nsteps) issue((s + 1) & 1);
+    const unsigned char* base = smem + (s & 1) * STAGE;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      u32x4 fa[TMT], fb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = ld16(base + b_rd[g] + j * 16 * 128);
+#pragma unroll
+      for (int i = 0; i < TMT; ++i) fa[i] = ld16(base + a_rd[g] + i * 16 * 128);
+#pragma unroll
+      for (int i = 0; i < TMT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
+                                                              acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------------------------
+  const int col = n0 + wn * 64 + 4 * c16;
+  const unsigned ldob = (unsigned)(p.ldo * ES), ldyb = (unsigned)(p.bn_ldy * ES);
+  bool tile_ok[TMT];
+  unsigned voff[TMT], yoff[TMT];
+  int ccol = col;
+  unsigned row_bytes = ldob;
+  if (p.mode == MODE_SHUFFLE) {
+    const int ab = col / p.shuf_c;
+    ccol = col - ab * p.shuf_c;
+    row_bytes = 2 * ldob;
+#pragma unroll
+    for (int i = 0; i < TMT; ++i) {
+      const int mb = m0 + (wm * TMT + i) * 16;
+      tile_ok[i] = mb < p.M;
+      int n, oy, ox;
+      decode(mb, n, oy, ox);
+      const unsigned pix = (unsigned)((n * 2 * p.Ho + 2 * oy + (ab >> 1)) * (2 * p.Wo) + 2 * ox + (ab & 1));
+      voff[i] = (pix + 8u * rb) * ldob + (unsigned)(ccol * ES);
+      yoff[i] = 0;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < TMT; ++i) {
+      const int mb = m0 + (wm * TMT + i) * 16;
+      tile_ok[i] = mb < p.M;
+      voff[i] = (unsigned)(mb + 4 * rb) * ldob + (unsigned)(col * ES);
+      yoff[i] = (unsigned)(mb + 4 * rb) * ldyb + (unsigned)(col * ES);
+    }
+  }
+  float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+  switch (p.mode) {
+    case MODE_STATS: epilogue16<MODE_STATS, TMT>(p, acc, tile_ok, voff, row_bytes, yoff, ldyb, ccol, s4, q4); break;
+    case MODE_AFFINE_RELU: epilogue16<MODE_AFFINE_RELU, TMT>(p, acc, tile_ok, voff, row_bytes, yoff, ldyb, ccol, s4, q4); break;
+    case MODE_BNBWD: epilogue16<MODE_BNBWD, TMT>(p, acc, tile_ok, voff, row_bytes, yoff, ldyb, ccol, s4, q4); break;
+    default: epilogue16<MODE_STORE, TMT>(p, acc, tile_ok, voff, row_bytes, yoff, ldyb, ccol, s4, q4); break;
+  }
+  if (p.mode == MODE_STATS || p.mode == MODE_BNBWD) {
+    const int nrow = (p.mode == MODE_BNBWD) ? 3 : 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                           // the four row groups of a lane column
+      s4[k] += __shfl_xor(s4[k], 16, 64); q4[k] += __shfl_xor(q4[k], 16, 64);
+      s4[k] += __shfl_xor(s4[k], 32, 64); q4[k] += __shfl_xor(q4[k], 32, 64);
+    }
+    __syncthreads();                                       // stage buffers are free
+    float* red = reinterpret_cast<float*>(smem);           // [wave][4 k][2][16 c]
+    if (rb == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        red[((wave * 4 + k) * 2 + 0) * 16 + c16] = s4[k];
+        red[((wave * 4 + k) * 2 + 1) * 16 + c16] = q4[k];
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int wn2 = tid >> 6, cc = tid & 63, c2 = cc >> 2, k = cc & 3;
+      float su = 0.f, sq = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < WM; ++w2) {
+        su += red[(((w2 * WN + wn2) * 4 + k) * 2 + 0) * 16 + c2];
+        sq += red[(((w2 * WN + wn2) * 4 + k) * 2 + 1) * 16 + c2];
+      }
+      p.stats[((long)mblk * nrow + 0) * p.Cout + n0 + tid] = su;
+      p.stats[((long)mblk * nrow + 1) * p.Cout + n0 + tid] = sq;
+      if (nrow == 3) p.stats[((long)mblk * 3 + 2) * p.Cout + n0 + tid] = 0.f;
+    }
+  }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int WM, int WN, int TMT>
+static int launch_dma16_cfg(IgemmParams& p, hipStream_t stream) {
+  constexpr int BM = WM * TMT * 16, BN = WN * 64;
+  constexpr int LDS = 2 * (BM + BN) * 128;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma16_kernel<WM, WN, TMT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(igemm_dma16_kernel) failed: %s", hipGetErrorString(e));
+      return UNETDC_ELAUNCH;
+    }
+    attr_done = true;
+  }
+  p.mblocks = ceil_div(p.M, BM);
+  p.nblocks = p.Cout / BN;
+  const long nwg = (long)p.mblocks * p.nblocks;
+  hipLaunchKernelGGL((igemm_dma16_kernel<WM, WN, TMT>), dim3((unsigned)nwg), dim3(WM * WN * 64), LDS, stream, p);
+  char nm[96];
+  snprintf(nm, sizeof(nm), "igemm_dma16_kernel<%d, %d, %d>", WM, WN, TMT);
+  note_kernel(nm);
+  return check_launch("igemm_dma16_kernel");
+}
+
+bool igemm_dma16_supported(const IgemmParams& p, int dtype) {
+  static int off = -1;                                   // UNETDC_MFMA16=0: the 32x32x16 kernels (A/B measurements)
+  if (off < 0) { const char* e = getenv("UNETDC_MFMA16"); off = (e && e[0] == '0') ? 1 : 0; }
+  if (off || dtype != UNETDC_BF16) return false;
+  if (p.M % 16 != 0) return false;
+  if (p.mode == MODE_SHUFFLE && p.Wo % 16 != 0) return false;
+  return true;
+}
+
+// cfg: 1 = 256x256 (8 waves), 2 = 256x128 (8 waves), 3 = 256x64 (4 waves) -- chosen by launch_igemm_dma
+int launch_igemm_dma16(IgemmParams& p, int cfg, hipStream_t stream) {
+  if (cfg == 1) return launch_dma16_cfg<2, 4, 8>(p, stream);
+  if (cfg == 2) return launch_dma16_cfg<4, 2, 4>(p, stream);
+  return launch_dma16_cfg<4, 1, 4>(p, stream);
+}
+
+}  // namespace unetdc
