@@ -88,7 +88,8 @@ def main(argv=None, parser=None):
         criterion = lambda pred, tgt: focal_dice_loss(pred, tgt, alpha=1.0, gamma=2.0, ratio=0.3)  # noqa: E731
     else:
         criterion = combined_loss
-    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)
+    # same update as the reference's torch.optim.Adam(lr) (train_DC_focal.py:224); fused = one multi-tensor kernel on the GPU
+    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, fused=next(model.parameters()).is_cuda)
 
     train_ds, val_ds, _ = make_datasets(args)
     if world > 1:                                           # each rank draws its own shard
