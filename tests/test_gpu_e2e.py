@@ -244,3 +244,29 @@ def test_full_size_train_step_bf16_properties():
     for k, p in model.named_parameters():
         if k.endswith(".0.bias") or k.endswith(".3.bias"):
             assert float(p.grad.abs().max()) < 1e-3 * gmax, k
+
+
+def test_eval_after_fused_adam_step_uses_updated_weights():
+    """torch.optim.Adam(fused=True) updates parameters without bumping their version counters: the packed bf16/fp32
+    weight images must still follow.  One fused step, then an eval forward on the HIP path == the CPU port evaluated
+    with the UPDATED state dict (and differs measurably from the pre-step output)."""
+    model, g = build_model("dc_c1", "train")
+    x, t = torch.from_numpy(g["train_x"]), torch.from_numpy(g["train_t"])
+    from utils.metrics_DC import focal_dice_loss
+    model = model.cuda().train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2, fused=True)
+    with torch.no_grad():
+        model.eval()
+        p_before = model(x.cuda()).cpu()
+        model.train()
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        focal_dice_loss(model(x.cuda()), t.cuda(), alpha=1.0, gamma=2.0, ratio=0.3).backward()
+        opt.step()
+    model.eval()
+    with torch.no_grad():
+        p_after = model(x.cuda()).cpu()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    p_ref = otc.unet_forward(x, sd, dict(model.DILATIONS), train=False)
+    assert float((p_after - p_ref).abs().max()) < 1e-4
+    assert float((p_after - p_before).abs().max()) > 1e-3          # the two Adam steps did change the output

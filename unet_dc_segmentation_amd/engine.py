@@ -192,8 +192,11 @@ class UNetEngine:
         return ent
 
     def _pack(self, need_dgrad):
-        """Re-pack the K-contiguous compute-type weight images when any parameter changed
-        (optimizer.step(), load_state_dict): ONE launch over a device-resident descriptor table."""
+        """Re-pack the K-contiguous compute-type weight images: ONE launch over a device-resident descriptor
+        table.  In training (need_dgrad) the images are rebuilt EVERY step -- fused optimizers such as
+        torch.optim.Adam(fused=True) update parameters without bumping their version counters, so a version
+        check would silently keep stale weights; in inference the version counters (load_state_dict, copy_)
+        decide."""
         import numpy as np
         ent = self._pack_entries()
         versions = tuple(w._version for w, *_ in ent)
@@ -208,7 +211,8 @@ class UNetEngine:
                 off += (a // 32) * (b // 32)                 # 32 x 32 channel tiles of this tensor
             self._pack_table = torch.from_numpy(tab.view(np.uint8).copy()).to(self.device)
             self._pack_total, self._pack_ptrs, self._pack_versions = off, ptrs, None
-        if self._pack_versions != versions:
+        if need_dgrad or getattr(self, "_pack_dirty", False) or self._pack_versions != versions:
+            self._pack_dirty = need_dgrad      # a training forward is usually followed by an optimizer step
             call("unetdc_pack_many", self._pack_table.data_ptr(), len(ent), self._pack_total, self.dt, _stream())
             self._pack_versions = versions
 
