@@ -374,7 +374,11 @@ def test_dgrad_with_fused_bn_backward_statistics(dtype, case):
     s1, s2 = gh.sum(dim=(0, 2, 3)), (gh * xh).sum(dim=(0, 2, 3))
     assert float((pc[0] - s1).abs().max()) <= tol * float(gh.abs().sum(dim=(0, 2, 3)).max())
     assert float((pc[1] - s2).abs().max()) <= tol * float((gh * xh).abs().sum(dim=(0, 2, 3)).max())
-    assert float(pc[2].abs().max()) == 0.0
+    # third row: the fused epilogue writes exact zeros (sum of xhat vanishes for batch statistics); the stand-alone
+    # reduction behind the first-generation kernels accumulates sum(xhat) itself
+    if float(pc[2].abs().max()) != 0.0:
+        s3 = xh.sum(dim=(0, 2, 3))
+        assert float((pc[2] - s3).abs().max()) <= tol * float(xh.abs().sum(dim=(0, 2, 3)).max())
     # bn_relu_bwd with the precomputed partial sums == bn_relu_bwd doing its own reduction
     f32 = dict(device="cuda", dtype=torch.float32)
     gd = gamma.cuda()

@@ -625,8 +625,12 @@ int launch_bn_bwd_reduce_only(BnBwdParams& p, float* parts, long parts_floats, i
   const int seg = cpp < 256 ? cpp : 256;
   UNETDC_REQUIRE(p.C % epc == 0 && 256 % seg == 0, "bn_bwd_reduce: C=%d unsupported", p.C);
   const long Q = (long)p.N * p.H * p.W;
-  const int nb = bn_bwd_blocks(Q, cpp);
-  UNETDC_REQUIRE((long)(nb + 64) * 3 * p.C <= parts_floats, "bn_bwd_reduce: partial buffer too small");
+  // the caller sized `parts` for the fused-epilogue producer (one row per 256 pixels + 64 spare rows); this
+  // stand-alone pass (grid-stride over pixels) takes as many workgroups as that buffer has rows for
+  int nb = bn_bwd_blocks(Q, cpp);
+  const long cap = parts_floats / (3L * p.C) - 64;
+  if (nb > cap) nb = (int)cap;
+  UNETDC_REQUIRE(nb >= 1, "bn_bwd_reduce: partial buffer too small");
   p.parts = parts;
   p.dpool = nullptr;
   const dim3 grid(nb, (cpp + seg - 1) / seg);
