@@ -31,8 +31,11 @@ __global__ __launch_bounds__(256) void colsum_stage_kernel(const float* __restri
 
 // Reduce `nparts` rows to at most 64 rows written at parts + nparts*L (caller provides 64 spare rows).
 // Returns pointer/rows of the reduced set through the out-params.
-int reduce_parts(const float* parts, int nparts, int L, const float** red_ptr, int* red_rows, hipStream_t stream) {
-  if (nparts <= 64) {
+// `direct` = row count up to which the consumer kernel reads the rows itself (64 for the serial finalizers; the
+// 32-lanes-per-channel BatchNorm finalizers take 512 rows = 16 loads per lane and save this launch).
+int reduce_parts(const float* parts, int nparts, int L, const float** red_ptr, int* red_rows, hipStream_t stream,
+                 int direct = 64) {
+  if (nparts <= direct) {
     *red_ptr = parts;
     *red_rows = nparts;
     return UNETDC_OK;
@@ -551,7 +554,7 @@ int launch_bn_finalize(const float* parts, int nparts, long count, const float* 
   UNETDC_REQUIRE(parts && gamma && beta && scale && shift && mean && rstd, "bn_finalize: null pointer");
   UNETDC_REQUIRE(nparts > 0 && count > 0 && C > 0, "bn_finalize: empty problem");
   const float* rp; int rows;
-  int rc = reduce_parts(parts, nparts, 2 * C, &rp, &rows, stream);
+  int rc = reduce_parts(parts, nparts, 2 * C, &rp, &rows, stream, 512);
   if (rc != UNETDC_OK) return rc;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, stream, rp, rows, (double)count, gamma,
                      beta, eps, momentum, rm, rv, scale, shift, mean, rstd, C);
@@ -672,13 +675,13 @@ int launch_bn_bwd(BnBwdParams& p, const float* gamma, float* dgamma, float* dbet
   const float* rp; int rows;
   if (pre_parts) {
     // the reduction was fused into the epilogue of the kernel that produced the gradient
-    rc = reduce_parts(pre_parts, pre_nparts, 3 * p.C, &rp, &rows, stream);
+    rc = reduce_parts(pre_parts, pre_nparts, 3 * p.C, &rp, &rows, stream, 512);
   } else {
     if (dtype == UNETDC_BF16) launch_bn_bwd_k<bf16_t>(p, pool, false, grid, stream);
     else launch_bn_bwd_k<float>(p, pool, false, grid, stream);
     rc = check_launch("bn_bwd_kernel(reduce)");
     if (rc != UNETDC_OK) return rc;
-    rc = reduce_parts(parts, nb, 3 * p.C, &rp, &rows, stream);
+    rc = reduce_parts(parts, nb, 3 * p.C, &rp, &rows, stream, 512);
   }
   if (rc != UNETDC_OK) return rc;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 7) / 8), dim3(256), 0, stream, rp, rows,
