@@ -4,14 +4,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from models.model_2 import UNetDC
 from utils.metrics_DC import focal_dice_loss
-from oracle import recipe
 
 bs, size = int(sys.argv[1]) if len(sys.argv) > 1 else 8, int(sys.argv[2]) if len(sys.argv) > 2 else 512
 torch.manual_seed(5)
 model = UNetDC(1, 1).cuda().train()
 model.set_compute_dtype(sys.argv[3] if len(sys.argv) > 3 else "bf16")
-x = recipe.seeded_input(6, (bs, 1, size, size)).cuda()
-t = recipe.seeded_target(7, (bs, 1, size, size)).cuda()
+g = torch.Generator().manual_seed(6)
+x = torch.rand(bs, 1, size, size, generator=g).cuda()
+t = (torch.rand(bs, 1, size, size, generator=g) > 0.7).float().cuda()
 snaps = []
 for _ in range(3):
     model.zero_grad(set_to_none=True)
