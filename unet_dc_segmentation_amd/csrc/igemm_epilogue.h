@@ -16,12 +16,12 @@
 //     flight per tile, in straight-line code so the compiler can count vmcnt instead of draining.
 //
 // BUILD NOTE (-fno-slp-vectorize, see build.py): with SLP vectorisation the channel-pair arithmetic of the
-// BatchNorm-backward statistics becomes v_pk_fma_f32 / v_pk_add_f32, and on MI355X that build was NOT
-// run-to-run deterministic: about one workgroup in 8192 dropped (or wrongly kept) the contribution of a
-// single pixel, always in the ODD channel of a pair (the high half of the packed result) and always in
-// lanes 48-63 -- the signature of the v_cmp that consumes the high half of a packed result two
-// instructions later seeing the previous register contents in its last pass.  The scalar build (0 v_pk_*
-// instructions) was bit-identical over 36 runs of the same probe (tools/det_op.py) and is as fast.
+// BatchNorm-backward statistics becomes packed fp32 (v_pk_fma_f32 / v_pk_add_f32), and on MI355X that build was
+// NOT run-to-run deterministic: about one workgroup in 8192 dropped (or wrongly kept) the contribution of a
+// single pixel, always in the ODD channel of a pair and always in lanes 48-63.  The root cause is not identified
+// (an isolated replay of the packed-FMA -> compare -> select sequence, tools/probes/pk_hazard.hip, is clean); the
+// scalar build (0 v_pk_* instructions) was bit-identical over 36 runs of tools/det_op.py and ever since, and is
+// as fast.  tests/test_gpu_ops.py guards it at the full layer sizes.
 #pragma once
 #include "kernels.h"
 
