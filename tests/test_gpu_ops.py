@@ -429,7 +429,7 @@ def test_dgrad_with_fused_column_sums(dtype, case):
 
 
 @pytest.mark.parametrize("case", [(8, 512, 512, 64, 64, 1), (8, 256, 256, 128, 128, 2), (8, 64, 64, 512, 512, 8),
-                                  (8, 512, 512, 128, 64, 1)])
+                                  (8, 512, 512, 128, 64, 1), (8, 32, 32, 1024, 1024, 16), (8, 128, 128, 256, 512, 1)])
 def test_fused_bn_backward_statistics_are_run_to_run_deterministic(case):
     """Full-size layers of the headline config (bs 8, 512x512): dgrad + fused BatchNorm-backward partial sums,
     six runs, bitwise identical output AND partial rows.  Regression test for a build whose packed-fp32
