@@ -18,97 +18,13 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-#include "igemm_epilogue.h"
+#include "igemm_epilogue16.h"
 #include "kernels.h"
 
 namespace unetdc {
 
 #define LDS_PTR16(p) ((__attribute__((address_space(3))) void*)(p))
 constexpr unsigned OOB16 = 0x80000000u;
-
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ u32x2 pack4_bf16(float a, float b, float c, float d) {
-  u32x2 r;
-  r[0] = OutPair<bf16_t>::pack(a, b);
-  r[1] = OutPair<bf16_t>::pack(c, d);
-  return r;
-}
-__device__ __forceinline__ void unpack4_bf16(const u32x2& r, float (&t)[4]) {
-  const unsigned int u0 = r[0], u1 = r[1];
-  t[0] = bits_f32(u0 << 16); t[1] = bits_f32(u0 & 0xffff0000u);
-  t[2] = bits_f32(u1 << 16); t[3] = bits_f32(u1 & 0xffff0000u);
-}
-
-// TMT M-tiles of 16 rows x 4 N-tiles of 16 channels per wave -> global memory (bf16)
-template <int MODE, int TMT>
-__device__ __forceinline__ void epilogue16(const IgemmParams& p, f32x4 (&acc)[TMT][4], const bool (&tile_ok)[TMT],
-                                           const unsigned (&voff)[TMT], unsigned row_bytes, const unsigned (&yoff)[TMT],
-                                           unsigned yrow_bytes, int ccol, float (&s)[4], float (&q)[4]) {
-  const __amdgpu_buffer_rsrc_t orr = whole_buffer(p.out);
-  const __amdgpu_buffer_rsrc_t yrr = whole_buffer(MODE == MODE_BNBWD ? p.bn_y : p.out);
-  float k0[4] = {0.f, 0.f, 0.f, 0.f}, k1[4] = {0.f, 0.f, 0.f, 0.f}, mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f};
-  if (MODE == MODE_AFFINE_RELU || MODE == MODE_BNBWD) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { k0[k] = p.scale[ccol + k]; k1[k] = p.shift[ccol + k]; }
-  } else if (p.bias) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) k1[k] = p.bias[ccol + k];
-  }
-  if (MODE == MODE_BNBWD) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { mu[k] = p.bn_mean[ccol + k]; rs[k] = p.bn_rstd[ccol + k]; }
-  }
-  constexpr int GRP = TMT < 4 ? TMT : 4;                  // tiles whose saved-output loads are in flight together
-#pragma unroll
-  for (int i0 = 0; i0 < TMT; i0 += GRP) {
-    u32x2 yraw[GRP][4];
-    if (MODE == MODE_BNBWD) {
-#pragma unroll
-      for (int ii = 0; ii < GRP; ++ii)
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-          yraw[ii][v] = tile_ok[i0 + ii] ? __builtin_amdgcn_raw_buffer_load_b64(yrr, yoff[i0 + ii], (unsigned)v * yrow_bytes, 0)
-                                         : u32x2{0u, 0u};
-    }
-#pragma unroll
-    for (int ii = 0; ii < GRP; ++ii) {
-      const int i = i0 + ii;
-      if (!tile_ok[i]) continue;
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        float x[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) x[k] = acc[i][k][v];
-        if (MODE == MODE_AFFINE_RELU) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) x[k] = fmaxf(fmaf(x[k], k0[k], k1[k]), 0.f);
-        } else if (MODE != MODE_BNBWD) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) x[k] += k1[k];
-        }
-        const u32x2 pk = pack4_bf16(x[0], x[1], x[2], x[3]);
-        __builtin_amdgcn_raw_buffer_store_b64(pk, orr, voff[i], (unsigned)v * row_bytes, 0);
-        if (MODE == MODE_STATS) {
-          float t[4];
-          unpack4_bf16(pk, t);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) { s[k] += t[k]; q[k] = fmaf(t[k], t[k], q[k]); }
-        } else if (MODE == MODE_BNBWD) {
-          float t[4], y[4];
-          unpack4_bf16(pk, t);
-          unpack4_bf16(yraw[ii][v], y);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float g = fmaf(y[k], k0[k], k1[k]) > 0.f ? t[k] : 0.f;
-            s[k] += g;
-            q[k] = fmaf(g, (y[k] - mu[k]) * rs[k], q[k]);
-          }
-        }
-      }
-    }
-  }
-}
-#endif
 
 // WM x WN waves; each wave owns (TMT*16) x 64 outputs (TMT x 4 MFMA 16x16 tiles).
 template <int WM, int WN, int TMT>
@@ -308,36 +224,7 @@ __global__ __launch_bounds__(512, 2) void igemm_dma16_kernel(const IgemmParams p
     case MODE_BNBWD: epilogue16<MODE_BNBWD, TMT>(p, acc, tile_ok, voff, row_bytes, yoff, ldyb, ccol, s4, q4); break;
     default: epilogue16<MODE_STORE, TMT>(p, acc, tile_ok, voff, row_bytes, yoff, ldyb, ccol, s4, q4); break;
   }
-  if (p.mode == MODE_STATS || p.mode == MODE_BNBWD) {
-    const int nrow = (p.mode == MODE_BNBWD) ? 3 : 2;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {                           // the four row groups of a lane column
-      s4[k] += __shfl_xor(s4[k], 16, 64); q4[k] += __shfl_xor(q4[k], 16, 64);
-      s4[k] += __shfl_xor(s4[k], 32, 64); q4[k] += __shfl_xor(q4[k], 32, 64);
-    }
-    __syncthreads();                                       // stage buffers are free
-    float* red = reinterpret_cast<float*>(smem);           // [wave][4 k][2][16 c]
-    if (rb == 0) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        red[((wave * 4 + k) * 2 + 0) * 16 + c16] = s4[k];
-        red[((wave * 4 + k) * 2 + 1) * 16 + c16] = q4[k];
-      }
-    }
-    __syncthreads();
-    if (tid < BN) {
-      const int wn2 = tid >> 6, cc = tid & 63, c2 = cc >> 2, k = cc & 3;
-      float su = 0.f, sq = 0.f;
-#pragma unroll
-      for (int w2 = 0; w2 < WM; ++w2) {
-        su += red[(((w2 * WN + wn2) * 4 + k) * 2 + 0) * 16 + c2];
-        sq += red[(((w2 * WN + wn2) * 4 + k) * 2 + 1) * 16 + c2];
-      }
-      p.stats[((long)mblk * nrow + 0) * p.Cout + n0 + tid] = su;
-      p.stats[((long)mblk * nrow + 1) * p.Cout + n0 + tid] = sq;
-      if (nrow == 3) p.stats[((long)mblk * 3 + 2) * p.Cout + n0 + tid] = 0.f;
-    }
-  }
+  if (p.mode == MODE_STATS || p.mode == MODE_BNBWD) write_stat_rows16<WM, WN>(p, smem, s4, q4, mblk, n0, tid, wave, c16, rb);
 #endif
 }
 
