@@ -37,6 +37,8 @@ CONV_CASES = [  # n, h, w, cin, cout, d
     (2, 32, 32, 64, 128, 16),    # d = 16 on a 32x32 map: tap skipping
     (1, 16, 16, 256, 64, 8),     # deep K, narrow N
     (1, 8, 8, 128, 256, 1),      # tiny map
+    (2, 48, 80, 64, 128, 2),     # map sizes that are not powers of two: division-based pixel decode everywhere
+    (3, 96, 160, 64, 64, 1),     # ... 46080 pixels = 180 block tiles; W = 160: five 32-pixel wgrad segments in fp32, per-tap kernel in bf16
     # >= 128K pixels, Cout 64/128, d <= 2: routed to the halo-patch kernel (igemm_halo.hip)
     (2, 256, 256, 64, 64, 1),    # 4-wave config, one K chunk, image borders on all sides
     (1, 264, 512, 128, 64, 1),   # two K chunks through a single patch buffer; H not a power of two
@@ -336,7 +338,7 @@ def test_pack_many_matches_per_layer_packers():
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("case", [(2, 16, 24, 64, 64, 1), (1, 32, 32, 128, 256, 4), (2, 256, 256, 64, 64, 1),
-                                  (1, 512, 256, 128, 64, 2)])
+                                  (1, 512, 256, 128, 64, 2), (2, 96, 160, 64, 64, 1), (2, 48, 80, 128, 128, 1)])
 def test_dgrad_with_fused_bn_backward_statistics(dtype, case):
     """conv dgrad whose epilogue also emits the BatchNorm-backward partial sums of the consuming stage
     (S1 = sum dx*[n>0], S2 = sum dx*[n>0]*xhat), and bn_relu_bwd consuming them instead of its own pass."""
