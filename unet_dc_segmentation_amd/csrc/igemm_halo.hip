@@ -377,7 +377,9 @@ bool igemm_halo_supported(const IgemmParams& p, int dtype) {
   const int d = p.offy[8];                       // taps are (ky-1)*d, (kx-1)*d
   if (d < 1 || d > 2) return false;
   if (p.offx[8] != d || p.offy[0] != -d || p.offx[0] != -d) return false;
-  if (!(p.Cout == 64 || p.Cout == 128)) return false;
+  static int wide = -1;                          // UNETDC_HALO_WIDE=1: also C_out = 256 / 512 (n-blocks of 128 over one patch each)
+  if (wide < 0) { const char* e = getenv("UNETDC_HALO_WIDE"); wide = (e && e[0] == '1') ? 1 : 0; }
+  if (!(p.Cout == 64 || p.Cout == 128 || (wide && p.Cout % 128 == 0 && p.Cout <= 512))) return false;
   if (p.Ho % TH != 0 || p.Wo % TW != 0) return false;
   if ((long)p.M < 256L * 512) return false;      // small maps: not worth a patch per tile
   const long es = dtype == UNETDC_BF16 ? 2 : 4;
@@ -441,7 +443,7 @@ static int launch_halo_cfg(IgemmParams& p, int d, hipStream_t stream) {
 
 int launch_igemm_halo(IgemmParams& p, int dtype, hipStream_t stream) {
   const int d = p.offy[8];
-  if (p.Cout == 128)
+  if (p.Cout % 128 == 0)
     return dtype == UNETDC_BF16 ? launch_halo_cfg<bf16_t, 2>(p, d, stream) : launch_halo_cfg<float, 2>(p, d, stream);
   return dtype == UNETDC_BF16 ? launch_halo_cfg<bf16_t, 1>(p, d, stream) : launch_halo_cfg<float, 1>(p, d, stream);
 }
