@@ -93,3 +93,43 @@ def test_data_parallel_world2_gloo():
     for p in procs:
         p.join(60)
     assert all(r[1] == "ok" for r in results), results
+
+
+def _train_worker(rank, world, port, q, args):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK=str(rank))
+        torch.set_num_threads(2)
+        import train_DC_focal as t
+        hist = t.main(args)
+        q.put((rank, "ok", hist))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: " + repr(e) + "\n" + traceback.format_exc(), None))
+
+
+@pytest.mark.timeout(900)
+def test_train_entry_world2_uneven_shards_and_early_stop(tmp_path):
+    """train_DC_focal.py under world size 2 (gloo, ATen-CPU path) with a training set whose length is NOT a multiple
+    of the world size and a patience of one epoch: every rank must run the same number of steps (equal shards), stop
+    in the same epoch (rank 0's validation Dice is broadcast) and hold bit-identical parameters after every epoch
+    (replicated init + averaged gradients + identical Adam state) -- none of which may hang."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    # 23 tiles -> 4 test + 4 val + 15 train: shards of 7 and 8 before truncation, 3 vs 4 steps at batch 2
+    args = ["--synthetic", "--synthetic_len", "23", "--img_size", "32", "--batch", "2", "--epochs", "4", "--patience", "1",
+            "--workers", "0", "--in_channels", "1", "--device", "cpu", "--lr", "1e-3", "--ckpt_path", str(tmp_path / "b.pth")]
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q, args)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=800) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+    assert all(r[1] == "ok" for r in results), results
+    h0, h1 = results[0][2], results[1][2]
+    assert len(h0) == len(h1) >= 1                          # both ranks left the loop in the same epoch
+    for a, b in zip(h0, h1):
+        assert a["val_dice"] == b["val_dice"]              # rank 0's value everywhere
+        assert a["param_checksum"] == b["param_checksum"]  # replicas bit-identical after each epoch

@@ -101,3 +101,72 @@ def test_hip_path_fails_loudly_without_library(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.UnetdcError, match="not found"):
         _lib.load()
+
+
+def test_calculate_metrics_matches_sklearn_and_plot(tmp_path):
+    """Five return values like the reference (utils/metrics_DC.py:75-85, which calls sklearn): checked against
+    sklearn itself, including the all-negative corner (zero_division=1)."""
+    from sklearn.metrics import confusion_matrix, f1_score, precision_score, recall_score
+    from utils.metrics_DC import calculate_metrics, plot_binary_confusion_matrix_with_metrics
+    g = torch.Generator().manual_seed(3)
+    for yt, yp in [((torch.rand(2, 1, 16, 16, generator=g) < 0.3).float(), torch.rand(2, 1, 16, 16, generator=g)),
+                   (torch.zeros(1, 1, 8, 8), torch.rand(1, 1, 8, 8, generator=g) * 0.2)]:
+        p, r, f1, sp, cm = calculate_metrics(yt, yp)
+        a, b = yt.view(-1).numpy(), (yp > 0.3).float().view(-1).numpy()
+        assert abs(p - precision_score(a, b, average="binary", zero_division=1)) < 1e-12
+        assert abs(r - recall_score(a, b, average="binary", zero_division=1)) < 1e-12
+        assert abs(f1 - f1_score(a, b, average="binary", zero_division=1)) < 1e-12
+        ref = confusion_matrix(a, b, labels=[0, 1])
+        assert np.array_equal(cm, ref) and cm.shape == (2, 2)
+        tn, fp = ref[0]
+        assert abs(sp - (tn / (tn + fp) if tn + fp else 0)) < 1e-12
+    out = plot_binary_confusion_matrix_with_metrics(cm, 0.9, path=str(tmp_path / "cm.png"))
+    assert os.path.getsize(out) > 1000
+
+
+def test_dataset_transform_conventions_and_worker_seeding(tmp_path):
+    """SegmentationDataset accepts the albumentations protocol the reference passes (keyword call, dict result,
+    utils/data_loader.py:59-62) and a plain callable; TrainAugment draws a different stream per DataLoader worker and
+    per epoch (the generator is derived from the worker's seed, which the DataLoader re-draws every epoch)."""
+    from torch.utils.data import DataLoader, Dataset
+    from utils.data_loader import SegmentationDataset, TrainAugment
+    rng = np.random.default_rng(5)
+    img = _disc_image(rng)
+    (tmp_path / "i").mkdir()
+    (tmp_path / "m").mkdir()
+    Image.fromarray(img).save(tmp_path / "i" / "a.png")
+    Image.fromarray(((img[..., 0] > 200) * 255).astype(np.uint8)).save(tmp_path / "m" / "a.png")
+    seen = {}
+
+    def kw_only(*, image, mask):                          # albumentations style
+        seen["kw"] = True
+        return {"image": torch.from_numpy(np.ascontiguousarray(image)).permute(2, 0, 1), "mask": mask}
+
+    def positional(img, mask):
+        seen["pos"] = True
+        return img[:, ::-1], mask[:, ::-1]
+    mk = lambda tf: SegmentationDataset(str(tmp_path / "i"), str(tmp_path / "m"), ["a.png"], ["a.png"],   # noqa: E731
+                                        transform=tf, size=32, radius=9)
+    base = mk(None)[0]
+    a = mk(kw_only)[0]
+    b = mk(positional)[0]
+    assert seen == {"kw": True, "pos": True}
+    assert a[0].shape == (3, 32, 32) and torch.equal(a[0], base[0]) and torch.equal(a[1], base[1])
+    assert torch.equal(b[0], base[0].flip(-1)) and torch.equal(b[1], base[1].flip(-1))
+    full = mk(TrainAugment(1))[0]
+    assert full[0].shape == (3, 32, 32) and full[1].shape == (1, 32, 32) and set(full[1].unique().tolist()) <= {0.0, 1.0}
+
+    class Probe(Dataset):                                 # returns the augmenter's first random draws in this process
+        def __init__(self):
+            self.aug = TrainAugment(7)
+
+        def __len__(self):
+            return 4
+
+        def __getitem__(self, i):
+            return torch.tensor(self.aug._generator().random(3))
+    loader = DataLoader(Probe(), batch_size=1, num_workers=2)
+    e1 = torch.cat(list(loader))
+    e2 = torch.cat(list(loader))
+    assert not torch.equal(e1[0], e1[1])                  # worker 0 and worker 1 differ
+    assert not torch.equal(e1, e2)                        # the next epoch does not replay the sequence

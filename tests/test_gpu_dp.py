@@ -60,6 +60,19 @@ def _worker(rank, world, port, q):
             worst = max(worst, err / scale)
             assert err <= 1e-5 * scale + 1e-9, (i, err, scale)
         assert dp.stats["buckets"] >= 2 and dp.stats["elems"] == sum(p.numel() for p in model.parameters())
+        # K optimizer steps on per-rank batches: the replicas must stay BITWISE identical (verification ii)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+        for k in range(3):
+            opt.zero_grad(set_to_none=True)
+            focal_dice_loss(model(xs[rank] * (1.0 - 0.1 * k)), ts[rank]).backward()
+            opt.step()
+        torch.cuda.synchronize()
+        chk = torch.stack([p.detach().double().sum() for p in model.parameters()]).cpu()
+        gathered = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(gathered, chk)
+        assert all(torch.equal(gathered[0], g) for g in gathered), "replicas diverged after 3 data-parallel steps"
+        assert not torch.equal(chk, torch.stack([v.double().sum() for k, v in sd0.items()
+                                                 if not ("running" in k or "num_batches" in k)]).cpu())
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok", worst, dp.stats["buckets"]))

@@ -295,16 +295,179 @@ def test_non_power_of_two_maps_fp32_train_step(shape):
     loss.backward()
     assert abs(loss.item() - float(loss_ref)) < 2e-5
     assert float((p.detach().cpu() - p_ref).abs().max()) < 1e-4
-    # Gradients: at random init this step is chaotic at the 1e-3 level -- the CPU fp32 evaluation itself is 2e-3..4e-3
-    # from fp64 on several tensors and moves by that much under 1-ulp input noise (ReLU / max-pool ties) -- so the
-    # yardstick is the worst error of the CPU fp32 evaluation over all tensors; the per-operator tests
-    # (test_gpu_ops.py, same map sizes) carry the tight per-kernel bounds.
-    errs_ref = [float((g_ref[k].double() - g64[k]).norm()) / max(float(g64[k].norm()), 1e-30) for k in g64
-                if not (k.endswith(".0.bias") or k.endswith(".3.bias"))]
-    yard = max(max(errs_ref), 1e-4)
+    # Gradients, per tensor: at random init this step is chaotic at the 1e-3 level (a ReLU / max-pool decision within
+    # rounding of a tie flips under ANY fp32 evaluation order and moves the gradients by a finite amount), so the
+    # yardstick of each tensor is the error of the CPU fp32 evaluation of THAT tensor against fp64 -- as evaluated, and
+    # under six 1-ulp perturbations of the input (same protocol as test_train_step_fp32_matches_golden_and_fp64).
+    def rel(a, k):
+        return float((a.double() - g64[k]).norm()) / max(float(g64[k].norm()), 1e-30)
+    yard = {k: rel(g_ref[k], k) for k in g64}
+    torch.manual_seed(0)
+    for _ in range(6):
+        xs = x * (1 + (torch.rand_like(x) - 0.5) * 2.4e-7)
+        _, _, gn = otc.train_step_grads(xs, t, {k: v.clone() for k, v in sd.items()}, dict(model.DILATIONS))
+        for k, v in gn.items():
+            yard[k] = max(yard[k], rel(v, k))
+    worst = 0.0
     for k, prm in model.named_parameters():
         if k.endswith(".0.bias") or k.endswith(".3.bias"):
+            assert float(prm.grad.abs().max()) < 1e-4, k       # exact value is 0 in front of train-mode BatchNorm
             continue
-        ref = g64[k]
-        e_hip = float((prm.grad.cpu().double() - ref).norm()) / max(float(ref.norm()), 1e-30)
-        assert e_hip < 4.0 * yard, (k, e_hip, yard)
+        e_hip = rel(prm.grad.cpu(), k)
+        worst = max(worst, e_hip / max(yard[k], 1e-7))
+        assert e_hip < max(4.0 * yard[k], 2e-5), (k, e_hip, yard[k])
+    print(f"[np2 {shape}] worst per-tensor gradient error ratio HIP / fp32 reference (both vs fp64) = {worst:.2f}")
+
+
+def test_backward_after_a_second_forward_is_refused():
+    """The HIP path keeps ONE set of activation buffers per module: a backward whose forward's activations were
+    overwritten by a later forward (train or eval) must raise instead of silently producing wrong gradients; an
+    in-place edit of the returned probabilities is caught by autograd's saved-tensor version check."""
+    from unet_dc_segmentation_amd._lib import UnetdcError
+    from utils.metrics_DC import focal_dice_loss
+    model, g = build_model("dc_c1", "train")
+    model = model.cuda().train()
+    x, t = torch.from_numpy(g["train_x"]).cuda(), torch.from_numpy(g["train_t"]).cuda()
+    p1 = model(x)
+    p2 = model(x * 0.5)                                   # overwrites the activations of the first forward
+    with pytest.raises(UnetdcError, match="overwritten by a later forward"):
+        focal_dice_loss(p1, t, alpha=1.0, gamma=2.0, ratio=0.3).backward()
+    focal_dice_loss(p2, t, alpha=1.0, gamma=2.0, ratio=0.3).backward()       # the latest forward is fine
+    g2 = model.dec1[0].weight.grad.clone()
+    model.zero_grad(set_to_none=True)
+    p3 = model(x * 0.5)
+    with torch.no_grad():
+        model.eval()
+        model(x)                                         # an eval forward in between also overwrites them
+        model.train()
+    with pytest.raises(UnetdcError, match="overwritten by a later forward"):
+        focal_dice_loss(p3, t, alpha=1.0, gamma=2.0, ratio=0.3).backward()
+    model.zero_grad(set_to_none=True)
+    p4 = model(x * 0.5)
+    loss = focal_dice_loss(p4, t, alpha=1.0, gamma=2.0, ratio=0.3)
+    loss.backward(retain_graph=True)
+    assert torch.equal(model.dec1[0].weight.grad, g2)    # same inputs, same weights: bitwise the same gradient
+    model.zero_grad(set_to_none=True)
+    loss.backward()                                      # second backward through the retained graph: buffers intact
+    assert torch.equal(model.dec1[0].weight.grad, g2)
+    p5 = model(x)
+    loss5 = focal_dice_loss(p5, t, alpha=1.0, gamma=2.0, ratio=0.3)
+    with torch.no_grad():
+        p5.mul_(0.5)                                     # in-place edit of an output the head backward reads
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        loss5.backward()
+
+
+def test_1024_tiles_bf16_train_step():
+    """BASELINE configs[4] per GPU: 4 x 1 x 1024 x 1024, bf16 storage / fp32 accumulate.  Bitwise run-to-run
+    determinism, finite gradients, and loss / probabilities against the bf16-storage evaluation of the CPU port."""
+    from models.model_2 import UNetDC
+    from utils.metrics_DC import focal_dice_loss
+    torch.manual_seed(31)
+    model = UNetDC(1, 1)
+    x = recipe.seeded_input(32, (4, 1, 1024, 1024))
+    t = recipe.seeded_target(33, (4, 1, 1024, 1024), frac=0.1)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    loss_emu, p_emu, gemu = otc.train_step_grads(x, t, sd, dict(model.DILATIONS), emulate_bf16=True)
+    model = model.cuda().train()
+    model.set_compute_dtype("bf16")
+    xc, tc = x.cuda(), t.cuda()
+    snaps = []
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        p = model(xc)
+        loss = focal_dice_loss(p, tc, alpha=1.0, gamma=2.0, ratio=0.3)
+        loss.backward()
+        snaps.append((loss.item(), [q.grad.clone() for q in model.parameters()]))
+    assert snaps[0][0] == snaps[1][0]
+    for a, b in zip(*[s[1] for s in snaps]):
+        assert torch.equal(a, b) and torch.isfinite(a).all()
+    assert abs(snaps[0][0] - float(loss_emu)) < 2e-3 * float(loss_emu)
+    assert float((p.detach().cpu() - p_emu).abs().max()) < 3e-2
+    for k, prm in model.named_parameters():
+        if k.startswith("dec1") and k.endswith(".weight") and prm.numel() >= 4096:
+            a, b = prm.grad.cpu().double().reshape(-1), gemu[k].double().reshape(-1)
+            assert float(a @ b / (a.norm() * b.norm())) > 0.999, k
+
+
+def test_1024_tile_eval_mask_fp32():
+    """One 1024 x 1024 tile, fp32 forward: pre-sigmoid within 1e-3 and mask equal to the CPU path outside the guard
+    band (same protocol as test_full_size_eval_mask_fp32; the 64 x 64 bottleneck map exercises d = 16 with all nine
+    taps in bounds for the interior pixels)."""
+    from models.model_2 import UNetDC
+    torch.manual_seed(41)
+    model = UNetDC(in_channels=1, out_channels=1)
+    recipe.perturb_bn(model.state_dict(), 42)
+    model.eval()
+    x = recipe.seeded_input(43, (1, 1, 1024, 1024))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        _, z_cpu = otc.unet_forward(x, sd, dict(model.DILATIONS), train=False, return_logits=True)
+    shift = recipe.LOGIT_THRESH - float(z_cpu.median())
+    with torch.no_grad():
+        model.out_conv.bias += shift
+    z_ref = (z_cpu + shift).double()
+    model = model.cuda()
+    with torch.no_grad():
+        p = model(x.cuda()).cpu()
+    z = logit(p)
+    err = float((z - z_ref).abs().max())
+    assert err < 1e-3, err
+    mask, mask_ref = (p > 0.3).numpy(), (z_ref > recipe.LOGIT_THRESH).numpy()
+    dist = (z_ref - recipe.LOGIT_THRESH).abs().numpy()
+    guard = dist > 1e-5
+    assert 0.3 < mask_ref.mean() < 0.7
+    assert np.array_equal(mask[guard], mask_ref[guard])
+    flips = np.logical_and(~guard, mask != mask_ref)
+    assert np.all(dist[flips] <= err + 1e-7)
+
+
+def test_quantify_cli_on_gpu_512(tmp_path):
+    """BASELINE configs[0] flow on the HIP path: quantify_droplets_batch.main() on 4 synthetic 512 x 512 PNGs, fp32.
+    The masks it writes must equal the CPU path's (the same entry point with DEVICE = "cpu") on every pixel outside
+    the guard band; droplet tables follow from the masks."""
+    import pandas as pd
+    from PIL import Image
+    import quantify_droplets_batch as q
+    from models.model_2 import UNetDC
+    rng = np.random.default_rng(0)
+    img_dir = tmp_path / "imgs"
+    img_dir.mkdir()
+    yy, xx = np.mgrid[0:512, 0:512]
+    for i in range(4):
+        img = (rng.random((512, 512, 3)) * 60).astype(np.uint8)
+        for _ in range(40):
+            cy, cx, r = rng.integers(8, 504), rng.integers(8, 504), rng.integers(2, 12)
+            img[(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = 230
+        Image.fromarray(img).save(img_dir / f"im{i}.png")
+    torch.manual_seed(0)
+    model = UNetDC(3, 1)
+    recipe.perturb_bn(model.state_dict(), 5)
+    # calibrate the head bias so that the mask is about half ones (random init is all-ones at 0.3, SURVEY section 0)
+    xs = torch.stack([q.preprocess(img_dir / f"im{i}.png", 15)[0] for i in range(4)])
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        _, z = otc.unet_forward(xs, sd, dict(model.DILATIONS), train=False, return_logits=True)
+        model.out_conv.bias += recipe.LOGIT_THRESH - float(z.median())
+        z = z + (recipe.LOGIT_THRESH - float(z.median()))
+    ckpt = tmp_path / "best_UNetDC_focal_model.pth"
+    torch.save(model.state_dict(), ckpt)
+    assert q.DEVICE == "cuda"
+    out = q.main(["--img_dir", str(img_dir), "--ckpt_path", str(ckpt), "--out_dir", str(tmp_path / "gpu"),
+                  "--batch", "4", "--prob_thresh", "0.3", "--skip_excel", "--skip_histogram",
+                  "--background_radius", "15", "--px_per_micron", "3.45"])
+    guard = ((z[:, 0].double() - recipe.LOGIT_THRESH).abs() > 1e-5).numpy()
+    ref = (z[:, 0].double() > recipe.LOGIT_THRESH).numpy()
+    for i in range(4):
+        m = np.array(Image.open(out / "predicted_masks" / f"im{i}_pred.png")) > 0
+        assert m.shape == (512, 512) and 0.2 < m.mean() < 0.8
+        assert np.array_equal(m[guard[i]], ref[i][guard[i]])
+    summary = pd.read_csv(out / "summary_per_image.csv")
+    assert list(summary.columns) == ["filename", "droplet_count", "total_area_px"] and len(summary) == 4
+    drops = pd.read_csv(out / "all_droplets.csv")
+    for i in range(4):
+        m = np.array(Image.open(out / "predicted_masks" / f"im{i}_pred.png")) > 0
+        d = q.quantify(m.astype(np.uint8), 1, 3.45)             # the scipy restatement of reference :81-95
+        mine = drops[drops["filename"] == f"im{i}.png"]
+        assert len(mine) == len(d) and abs(mine["area"].sum() - d["area"].sum()) < 1e-9
+        assert int(summary[summary["filename"] == f"im{i}.png"]["droplet_count"].iloc[0]) == len(d)

@@ -97,6 +97,7 @@ def e2e_fixture(cls, cin, seed, tag, met, hw=32):
 
 
 def op_fixtures(met):
+    torch.manual_seed(20260407)          # ConvTranspose2d / Conv2d below draw their default init from the GLOBAL RNG
     g = torch.Generator().manual_seed(7)
     out = {}
     # dilated 3x3 conv forward/backward at three dilations on a ragged (non-square) map

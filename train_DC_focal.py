@@ -19,7 +19,7 @@ import torch
 from torch.utils.data import DataLoader, Subset
 
 from unet_dc_segmentation_amd import dp as dpmod
-from utils.data_loader import SegmentationDataset, SyntheticDropletDataset, flip_rotate_augment
+from utils.data_loader import SegmentationDataset, SyntheticDropletDataset, TrainAugment
 from utils.metrics_DC import combined_loss, dice_coef, focal_dice_loss
 
 
@@ -67,7 +67,7 @@ def make_datasets(args):
     tr, va, te = pick(idx[n_test + n_val:]), pick(idx[n_test:n_test + n_val]), pick(idx[:n_test])
     mk = lambda pair, tf: SegmentationDataset(args.image_dir, args.mask_dir, pair[0], pair[1], transform=tf,  # noqa: E731
                                               size=args.img_size)
-    return mk(tr, flip_rotate_augment(args.seed)), mk(va, None), mk(te, None)
+    return mk(tr, TrainAugment(args.seed)), mk(va, None), mk(te, None)
 
 
 def main(argv=None, parser=None):
@@ -92,8 +92,12 @@ def main(argv=None, parser=None):
     optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, fused=next(model.parameters()).is_cuda)
 
     train_ds, val_ds, _ = make_datasets(args)
-    if world > 1:                                           # each rank draws its own shard
-        train_ds = Subset(train_ds, list(range(rank, len(train_ds), world)))
+    if world > 1:
+        # each rank draws its own shard; shards are truncated to EQUAL length (as DistributedSampler with
+        # drop_last does) so that every rank runs the same number of steps -- an extra step on one rank would
+        # leave its gradient all-reduce without partners
+        per_rank = len(train_ds) // world
+        train_ds = Subset(train_ds, list(range(rank, per_rank * world, world)))
     pin = device.type == "cuda"
     train_loader = DataLoader(train_ds, batch_size=args.batch, shuffle=True, num_workers=args.workers,
                               pin_memory=pin, drop_last=True)
@@ -129,6 +133,8 @@ def main(argv=None, parser=None):
         nb = max(1, min(len(train_loader), args.steps or len(train_loader)))
         dt = time.time() - t0
         # -------- validation --------
+        if wrapper is not None:
+            wrapper.broadcast_buffers()                     # rank 0's BatchNorm running statistics everywhere
         model.eval()
         va_loss = va_dice = 0.0
         vc = vt = 0
@@ -145,6 +151,13 @@ def main(argv=None, parser=None):
         rec = dict(epoch=epoch + 1, train_loss=tr_loss / nb, val_loss=va_loss / nv, train_dice=tr_dice / nb,
                    val_dice=va_dice / nv, train_acc=correct / max(total, 1), val_acc=vc / max(vt, 1),
                    images_per_sec=seen * world / max(dt, 1e-9))
+        if world > 1:
+            # replicas must stay identical: one checksum per rank and epoch (compared by tests/test_dp_gloo.py)
+            with torch.no_grad():
+                rec["param_checksum"] = float(sum(p.double().sum() for p in model.parameters()))
+            # early stopping / checkpointing are decided from rank 0's validation Dice on every rank, so all ranks
+            # leave the loop in the same epoch (a rank that stopped alone would strand the others in all_reduce)
+            rec["val_dice"] = dpmod.broadcast_scalar(rec["val_dice"], device)
         history.append(rec)
         if rank == 0:
             print(f"Epoch {epoch + 1}/{args.epochs} | Train Loss: {rec['train_loss']:.4f}, Val Loss: {rec['val_loss']:.4f}, "

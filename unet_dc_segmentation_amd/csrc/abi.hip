@@ -174,11 +174,10 @@ int unetdc_convT2x2_dgrad_bnstats(const void* dup, int lddup, const void* w_dgra
 
 int64_t unetdc_conv3x3_wgrad_workspace(int n, int h, int w, int cin, int cout, int dtype) {
   long b = wgrad_workspace_bytes((long)n * h * w, cout, cin, 9, dtype);
-  if (w % 32 == 0 && h >= 8) {          // the tap-fused kernel may be chosen
-    const long f = wgrad_fused_workspace_bytes(n, h, w, cout, cin, dtype);
-    if (f > b) b = f;
-  }
-  return b;
+  // the tap-fused kernel may be chosen (launch_wgrad decides with wgrad_fused_supported; the query returns 0 for
+  // shapes that kernel never takes, so the same condition governs both sides)
+  const long f = wgrad_fused_workspace_bytes(n, h, w, cout, cin, dtype);
+  return f > b ? f : b;
 }
 
 int unetdc_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,

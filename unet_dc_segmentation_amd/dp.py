@@ -2,9 +2,13 @@
 overlapped with the backward pass.
 
 The reference is single-device (train_DC_focal.py:208); this is the new exchange step that
-BASELINE config 3 asks for.  Semantics = DistributedDataParallel defaults:
-replicated parameters (rank 0 broadcast at start), per-rank BatchNorm statistics (the reference uses
-plain BatchNorm2d, models/model_2.py:45,52, no SyncBN), gradients averaged over ranks.
+BASELINE config 3 asks for.  Semantics: replicated parameters (rank 0 broadcast at
+start), gradients averaged over ranks, per-rank BatchNorm BATCH statistics (the reference uses plain
+BatchNorm2d, models/model_2.py:45,52, no SyncBN).  BatchNorm RUNNING statistics drift apart between ranks
+during an epoch; ``broadcast_buffers()`` makes rank 0's the common ones (DistributedDataParallel does that
+before every forward with its default broadcast_buffers=True; here the caller does it once before
+validation / checkpointing, which is where running statistics are read -- train_DC_focal.py), and
+``broadcast_scalar`` lets every rank take control-flow decisions (early stopping) from rank 0's value.
 
 Mechanics: the HIP backward (engine.py) writes all gradients into ONE flat fp32 buffer in
 ``parameters()`` order and calls ``grad_ready_hook(flat, lo, hi)`` after the kernels of each block
@@ -46,6 +50,14 @@ class DataParallel:
         """Rank 0's parameters and buffers become everyone's (identical replicas at step 0)."""
         with torch.no_grad():
             for t in list(self.model.parameters()) + list(self.model.buffers()):
+                dist.broadcast(t.data, src=0, group=self.pg)
+
+    def broadcast_buffers(self):
+        """Rank 0's buffers (BatchNorm running_mean / running_var / num_batches_tracked) become everyone's."""
+        if self.world == 1:
+            return
+        with torch.no_grad():
+            for t in self.model.buffers():
                 dist.broadcast(t.data, src=0, group=self.pg)
 
     # -------------------------------------------------------------- gradient exchange
@@ -103,6 +115,17 @@ class DataParallel:
         for p in params:
             p.grad.copy_(flat[o:o + p.numel()].view_as(p.grad))
             o += p.numel()
+
+
+def broadcast_scalar(value, device="cpu", src=0, group=None):
+    """Rank ``src``'s Python float on every rank (no-op without an initialised process group)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return float(value)
+    if dist.get_backend(group) == "gloo":
+        device = "cpu"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.broadcast(t, src=src, group=group)
+    return float(t.item())
 
 
 def init_from_env(backend=None):

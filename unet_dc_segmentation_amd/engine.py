@@ -177,8 +177,11 @@ class UNetEngine:
         need = max(need, lib.unetdc_head_bwd_workspace(N, H, W, 64, self.oc, self.dt))
         self.ws_bytes = int(need)
         self.workspace = None
-        self.probs = None
-        self.x_saved = None
+        # Saved-for-backward activations live in this engine's buffers (one set, sized for 288 GB of HBM, nothing is
+        # recomputed); `generation` counts forwards so that a backward can tell whether ITS forward's activations
+        # are still the ones in the buffers (see _UNetFunction.backward).
+        self.generation = 0
+        self._trained = False          # a train-mode forward has run: optimizer steps may follow at any time
 
     # ------------------------------------------------------------------ weight caches
     def _pack_entries(self):
@@ -191,12 +194,24 @@ class UNetEngine:
             ent.append((u["mod"].weight, u["w_fwd"], u["w_dgrad"], u["cin"], u["cout"], 1))
         return ent
 
+    def invalidate_weight_cache(self):
+        """Force the next forward to rebuild the packed weight images (call after writing parameters through a
+        path that bumps no version counter)."""
+        self._pack_versions = None
+
+    def weights_fresh(self, versions=None):
+        """Called by an optimizer that writes the packed images itself (FusedAdam, optim.py): the next forward
+        needs no re-pack."""
+        self._pack_fresh = True
+
     def _pack(self, need_dgrad):
         """Re-pack the K-contiguous compute-type weight images: ONE launch over a device-resident descriptor
-        table.  In training (need_dgrad) the images are rebuilt EVERY step -- fused optimizers such as
-        torch.optim.Adam(fused=True) update parameters without bumping their version counters, so a version
-        check would silently keep stale weights; in inference the version counters (load_state_dict, copy_)
-        decide."""
+        table.  Fused optimizers such as torch.optim.Adam(fused=True) update parameters WITHOUT bumping their
+        version counters, so once a train-mode forward has run on this engine (an optimizer may be stepping the
+        parameters) the images are rebuilt on every forward, eval-mode ones included (train fwd, eval fwd,
+        opt.step(), eval fwd must not see stale weights; the launch costs ~0.1 ms); in a pure-inference process
+        the version counters (load_state_dict, copy_) decide.  An optimizer that writes the images itself
+        (unet_dc_segmentation_amd.optim.FusedAdam) announces it through weights_fresh() and the pack is skipped."""
         import numpy as np
         ent = self._pack_entries()
         versions = tuple(w._version for w, *_ in ent)
@@ -211,8 +226,13 @@ class UNetEngine:
                 off += (a // 32) * (b // 32)                 # 32 x 32 channel tiles of this tensor
             self._pack_table = torch.from_numpy(tab.view(np.uint8).copy()).to(self.device)
             self._pack_total, self._pack_ptrs, self._pack_versions = off, ptrs, None
-        if need_dgrad or getattr(self, "_pack_dirty", False) or self._pack_versions != versions:
-            self._pack_dirty = need_dgrad      # a training forward is usually followed by an optimizer step
+        self._trained = self._trained or need_dgrad
+        if getattr(self, "_pack_fresh", False) and self._pack_versions is not None:
+            self._pack_fresh = False           # the optimizer step just wrote both images
+            self._pack_versions = versions
+            return
+        self._pack_fresh = False
+        if self._trained or self._pack_versions != versions:
             call("unetdc_pack_many", self._pack_table.data_ptr(), len(ent), self._pack_total, self.dt, _stream())
             self._pack_versions = versions
 
@@ -280,6 +300,7 @@ class UNetEngine:
                      pooled.data_ptr(), pooled.stride(0), N, h, w, st.cout, self.dt, s)
 
     def forward(self, x, train):
+        self.generation += 1               # every forward overwrites the activation buffers
         self._pack(need_dgrad=train)
         self._nbt = []
         s = _stream()
@@ -429,8 +450,8 @@ class UNetEngine:
             hi = self.poffs[self.pindex[id(ps[-1])]] + ps[-1].numel()
             hook(flat, lo, hi)
 
-    def backward(self, dprobs):
-        """dprobs: [N, OC, H, W] fp32.  Returns the flat fp32 gradient buffer (parameters() order)."""
+    def backward(self, dprobs, probs):
+        """dprobs, probs: [N, OC, H, W] fp32.  Returns the flat fp32 gradient buffer (parameters() order)."""
         self._ensure_grad_bufs()
         s = _stream()
         N = self.N
@@ -440,7 +461,7 @@ class UNetEngine:
         dprobs = dprobs.contiguous()
         oc = self.model.out_conv
         da = g[("da", 0)]
-        call("unetdc_head_bwd", dprobs.data_ptr(), self.probs.data_ptr(), self.head_in.data_ptr(),
+        call("unetdc_head_bwd", dprobs.data_ptr(), probs.data_ptr(), self.head_in.data_ptr(),
              self.head_in.stride(0), oc.weight.data_ptr(), da.data_ptr(), da.stride(0),
              self._gview(flat, oc.weight).data_ptr(), self._gview(flat, oc.bias).data_ptr(), ws, wsb,
              N, self.H, self.W, 64, self.oc, self.dt, s)
@@ -496,15 +517,24 @@ class _UNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, engine, *params):
         probs = engine.forward(x, train=True)
-        engine.probs = probs
-        engine.x_saved = x
         ctx.engine = engine
+        ctx.generation = engine.generation
+        # x (read by the first layer's weight gradient) and probs (read by the head backward) go through autograd's
+        # saved-tensor machinery so that an in-place edit of either between forward and backward is detected
+        ctx.save_for_backward(x, probs)
         return probs
 
     @staticmethod
     def backward(ctx, dprobs):
         eng = ctx.engine
-        flat = eng.backward(dprobs)
+        if eng.generation != ctx.generation:
+            raise _lib.UnetdcError(
+                "backward through a U-Net forward whose saved activations were overwritten by a later forward of "
+                "the same module (forward #%d, buffers now hold #%d): the HIP path keeps ONE set of activation "
+                "buffers per module, so run backward before the next forward (train or eval) of that module"
+                % (ctx.generation, eng.generation))
+        x, probs = ctx.saved_tensors
+        flat = eng.backward(dprobs, probs)
         finish = eng.model.grad_sync_finish
         if finish is not None:           # data parallel: wait (stream-side) for the bucket all-reduces
             finish()

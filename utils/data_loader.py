@@ -4,6 +4,9 @@ Off the hot path (CPU image prep): provided so the kept 
 end to end.  cv2 / albumentations are optional; without them the same operations run on
 PIL + SciPy (grey opening with an elliptical footprint == cv2.MORPH_OPEN with MORPH_ELLIPSE).
 Reference lines: rolling_ball_correction_rgb :11-24, SegmentationDataset :26-76.
+``transform`` may follow the albumentations protocol (keyword call, dict result -- what the reference passes)
+or be a plain ``(img, mask) -> (img, mask)`` callable; :class:`TrainAugment` restates the reference's
+augmentation list (train_DC_focal.py:183-190) on numpy / SciPy.
 """
 from __future__ import annotations
 
@@ -84,9 +87,11 @@ class SegmentationDataset(Dataset):
         img = resize_image(img, self.size).astype(np.float32) / 255.0
         mask = resize_image(mask, self.size, nearest=True)
         if self.transform is not None:
-            img, mask = self.transform(img, mask)
-        img_t = torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1).float()
-        mask_t = torch.from_numpy(np.ascontiguousarray(mask)).float().unsqueeze(0)
+            img, mask = _apply_transform(self.transform, img, mask)
+        img_t = _to_chw_tensor(img)
+        mask_t = torch.as_tensor(np.ascontiguousarray(mask)).float()
+        if mask_t.ndim == 2:
+            mask_t = mask_t.unsqueeze(0)
         out = [img_t, mask_t]
         if self.return_orig_size:
             out.append((oh, ow))
@@ -95,12 +100,54 @@ class SegmentationDataset(Dataset):
         return tuple(out)
 
 
-def flip_rotate_augment(seed=0):
-    """Horizontal/vertical flip + 90-degree rotation (the geometric part of the reference's
-    augmentation list, train_DC_focal.py:183-190), as a plain (img, mask) -> (img, mask) callable."""
-    rng = np.random.default_rng(seed)
+def _apply_transform(transform, img, mask):
+    """Both call conventions: the albumentations protocol the reference uses
+    (``transform(image=img, mask=mask) -> {"image": ..., "mask": ...}``, utils/data_loader.py:59-62) and a plain
+    ``(img, mask) -> (img, mask)`` callable."""
+    try:
+        out = transform(image=img, mask=mask)
+    except TypeError:
+        out = transform(img, mask)
+    if isinstance(out, dict):
+        return out["image"], out["mask"]
+    return out
 
-    def f(img, mask):
+
+def _to_chw_tensor(img):
+    """HWC numpy (or an already-CHW tensor, as albumentations' ToTensorV2 returns) -> CHW float tensor."""
+    if torch.is_tensor(img):
+        return img.float()
+    return torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1).float()
+
+
+class TrainAugment:
+    """The reference's training augmentation list (train_DC_focal.py:183-190) without albumentations:
+    HorizontalFlip(0.5), VerticalFlip(0.2), RandomRotate90(0.5), RandomBrightnessContrast(0.2) (limits 0.2,
+    float images: ``clip(alpha*img + beta*max, 0, 1)``), ElasticTransform(alpha=1, sigma=50, p=0.3).
+    Callable both ways (``t(img, mask)`` and ``t(image=img, mask=mask)``).
+
+    The random stream is seeded per DataLoader worker AND per epoch: each worker process derives its generator
+    from ``torch.utils.data.get_worker_info().seed`` (base_seed + worker id, re-drawn by the DataLoader every
+    epoch), so workers and epochs do not replay one sequence; in the main process (``num_workers=0``) one
+    generator seeded with ``seed`` simply runs on across epochs."""
+
+    def __init__(self, seed=0, brightness_contrast=True, elastic=True):
+        self.seed, self.bc, self.elastic = int(seed), brightness_contrast, elastic
+        self._rng, self._key = None, None
+
+    def _generator(self):
+        info = torch.utils.data.get_worker_info()
+        key = ("worker", info.id, info.seed) if info is not None else ("main", os.getpid())
+        if self._rng is None or self._key != key:
+            entropy = [self.seed, info.seed & 0xFFFFFFFF, info.id] if info is not None else [self.seed]
+            self._rng, self._key = np.random.default_rng(entropy), key
+        return self._rng
+
+    def __call__(self, img=None, mask=None, *, image=None):
+        as_dict = image is not None
+        if as_dict:
+            img = image
+        rng = self._generator()
         if rng.random() < 0.5:
             img, mask = img[:, ::-1], mask[:, ::-1]
         if rng.random() < 0.2:
@@ -108,8 +155,35 @@ def flip_rotate_augment(seed=0):
         if rng.random() < 0.5:
             k = int(rng.integers(1, 4))
             img, mask = np.rot90(img, k, (0, 1)), np.rot90(mask, k, (0, 1))
+        if self.bc and rng.random() < 0.2:
+            alpha, beta = 1.0 + rng.uniform(-0.2, 0.2), rng.uniform(-0.2, 0.2)
+            img = np.clip(alpha * img + beta * float(img.max() if img.size else 1.0), 0.0, 1.0).astype(np.float32)
+        if self.elastic and rng.random() < 0.3:
+            img, mask = _elastic(img, mask, rng, alpha=1.0, sigma=50.0)
+        if as_dict:
+            return {"image": img, "mask": mask}
         return img, mask
-    return f
+
+
+def _elastic(img, mask, rng, alpha, sigma):
+    """Elastic deformation: smooth random displacement field (Gaussian sigma) scaled by alpha; image bilinear,
+    mask nearest (Simard et al. 2003 as albumentations implements it)."""
+    from scipy import ndimage
+    h, w = img.shape[:2]
+    dx = ndimage.gaussian_filter(rng.random((h, w)) * 2 - 1, sigma, mode="constant") * alpha
+    dy = ndimage.gaussian_filter(rng.random((h, w)) * 2 - 1, sigma, mode="constant") * alpha
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    coords = [yy + dy, xx + dx]
+    img = np.ascontiguousarray(img)
+    out = np.stack([ndimage.map_coordinates(img[..., c], coords, order=1, mode="reflect")
+                    for c in range(img.shape[2])], axis=-1).astype(img.dtype)
+    m = ndimage.map_coordinates(np.ascontiguousarray(mask), coords, order=0, mode="reflect").astype(mask.dtype)
+    return out, m
+
+
+def flip_rotate_augment(seed=0):
+    """The geometric part only (flips + 90-degree rotations) of the reference's augmentation list."""
+    return TrainAugment(seed, brightness_contrast=False, elastic=False)
 
 
 class SyntheticDropletDataset(Dataset):

@@ -4,7 +4,9 @@
 The autograd of :func:`focal_dice_loss` produces dL/dprobs, which is the input of the HIP
 backward pass (head backward kernel).  Reference lines: dice_loss :11-17, combined_loss :19-22,
 dice_coef :24-29, FocalLoss :31-63, focal_dice_loss :65-73, calculate_metrics :75-85.
-The seaborn confusion-matrix plot (:87-116) is reporting-only and out of scope.
+calculate_metrics returns the reference's five values (precision, recall, F1, specificity, 2x2 confusion
+matrix laid out like sklearn's: [[tn, fp], [fn, tp]]); plot_binary_confusion_matrix_with_metrics (:87-116) draws
+the same annotated heat map with matplotlib alone (seaborn is not a dependency here).
 """
 from __future__ import annotations
 
@@ -70,13 +72,46 @@ def focal_dice_loss(pred, target, alpha=1.0, gamma=2.0, ratio=0.3):
 
 
 def calculate_metrics(y_true, y_pred):
-    """precision / recall / F1 / specificity of the 0.3-thresholded prediction (zero_division=1)."""
+    """precision / recall / F1 / specificity of the 0.3-thresholded prediction (zero_division=1) and the
+    2x2 confusion matrix [[tn, fp], [fn, tp]] (reference :75-85 via sklearn; same numbers, no sklearn needed)."""
     yp = (y_pred > 0.3).reshape(-1).cpu().numpy().astype(bool)
     yt = (y_true.reshape(-1).cpu().numpy() > 0.5)
-    tp = float(np.sum(yp & yt)); fp = float(np.sum(yp & ~yt))
-    fn = float(np.sum(~yp & yt)); tn = float(np.sum(~yp & ~yt))
+    tp = int(np.sum(yp & yt)); fp = int(np.sum(yp & ~yt))
+    fn = int(np.sum(~yp & yt)); tn = int(np.sum(~yp & ~yt))
     precision = tp / (tp + fp) if tp + fp > 0 else 1.0
     recall = tp / (tp + fn) if tp + fn > 0 else 1.0
-    f1 = 2 * precision * recall / (precision + recall) if precision + recall > 0 else 0.0
-    specificity = tn / (tn + fp) if tn + fp > 0 else 0.0
-    return precision, recall, f1, specificity
+    # sklearn's f1_score(zero_division=1): 1.0 when there are no positives at all, 0.0 when only p + r == 0
+    if tp + fp + fn == 0:
+        f1 = 1.0
+    else:
+        f1 = 2 * precision * recall / (precision + recall) if precision + recall > 0 else 0.0
+    specificity = tn / (tn + fp) if tn + fp > 0 else 0
+    conf_matrix = np.array([[tn, fp], [fn, tp]], dtype=np.int64)
+    return precision, recall, f1, specificity, conf_matrix
+
+
+def plot_binary_confusion_matrix_with_metrics(cm, accuracy, path="confusion_matrix_.png"):
+    """2x2 confusion matrix with per-class precision / recall / specificity on the diagonal and the overall
+    accuracy in the title, saved to ``confusion_matrix_.png`` (reference :87-116; matplotlib only)."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    tn, fp, fn, tp = (int(v) for v in np.asarray(cm).ravel())
+    ratio = lambda a, b: a / b if b > 0 else 0                                  # noqa: E731
+    annot = [[f"{tn}\nPr={ratio(tn, tn + fn):.2f}\nRec={ratio(tn, tn + fp):.2f}\nSp={ratio(tp, tp + fp):.2f}", f"{fp}"],
+             [f"{fn}", f"{tp}\nPr={ratio(tp, tp + fp):.2f}\nRec={ratio(tp, tp + fn):.2f}\nSp={ratio(tn, tn + fn):.2f}"]]
+    fig, ax = plt.subplots(figsize=(6, 5))
+    im = ax.imshow(np.asarray(cm, dtype=float), cmap="Blues")
+    fig.colorbar(im, ax=ax)
+    ax.set_xticks([0, 1], labels=["Negative", "Positive"])
+    ax.set_yticks([0, 1], labels=["Negative", "Positive"])
+    for i in range(2):
+        for j in range(2):
+            ax.text(j, i, annot[i][j], ha="center", va="center")
+    ax.set_title(f"Overall Accuracy: {accuracy:.3f}")
+    ax.set_xlabel("Predicted")
+    ax.set_ylabel("Actual")
+    fig.tight_layout()
+    fig.savefig(path)
+    plt.close(fig)
+    return path
