@@ -6,12 +6,19 @@ batch 8 per GPU, bf16 storage / fp32 accumulate (BASELINE.json metric, configs[2
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+With ``--gpus N`` (N > 1) and no torchrun environment, bench.py launches its own N ranks: the parent -- before any
+HIP call -- checks that N devices exist (else it exits non-zero: it never reports a one-rank number as an N-GPU
+one), starts N child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's JSON line and
+fails if any rank fails.
+
 Prints ONE JSON line on rank 0.  Besides the contract fields it carries
   roofline     -- the dominant kernel (bf16 implicit-GEMM conv): algorithmic dense FLOPs per launch /
                   average launch time measured live with HIP events on the launch stream over the
                   timed steps, against the 2.5 PFLOP/s dense bf16 MFMA peak;
+  hbm_leg      -- the HBM-bound kernels (BatchNorm passes, first layer, head): algorithmic bytes / launch time from a
+                  short HIP-event-instrumented pass after the timed region, against the 8 TB/s HBM peak;
   cpu_baseline -- the CPU port of the reference path (oracle/unetdc_torch_cpu.py, the same ATen ops
-                  the reference calls) timed on this host's cores on a bounded sample (N = 1 only).
+                  the reference calls) timed on this host's cores on a bounded sample (N = 1 only): median of 3 steps.
 Everything inside the timed region is real work: no step is skipped, the optimizer step and the
 weight re-packing it triggers are included; the reference loop's per-step .item()/.cpu() syncs
 (train_DC_focal.py:257-269) are not part of the metric and are excluded.
@@ -80,21 +87,26 @@ def igemm_flops(name, a, es=2):
 
 
 def pmc_traffic(kernel):
-    """Per-launch bytes past the L2 for `kernel` from the committed rocprofv3 PMC summary (separate
-    FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 correction on the read side) or None."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        table = json.load(open(path))["kernels"]
-    except (OSError, ValueError, KeyError):
-        return None
-    # rocprofv3 prints Itanium-mangled names for the __bf16 instantiations (c++filt cannot demangle
-    # DF16b), e.g. igemm_dma_kernel<__bf16, 2, 4, 4> -> igemm_dma_kernelIDF16bLi2ELi4ELi4EE
-    base, _, targs = kernel.partition("<")
-    frag = base + "I" + "".join("DF16b" if a.strip() == "__bf16" else ("f" if a.strip() == "float" else f"Li{a.strip()}E")
-                                for a in targs.rstrip(">").split(",")) + "E"
-    for sym, v in table.items():
-        if frag in sym or kernel in sym:
-            return v["bytes_corrected"]
+    """Per-launch bytes past the L2 for `kernel` from the committed rocprofv3 PMC summary (separate FETCH_SIZE /
+    WRITE_SIZE passes, gfx950 x2 correction on the read side; tools/pmc_traffic.sh), or None -- also None when the
+    summary was measured on different kernel sources than the ones built here (source-hash stamp)."""
+    for tag in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
+        try:
+            doc = json.load(open(path))
+            table = doc["kernels"]
+        except (OSError, ValueError, KeyError):
+            continue
+        if doc.get("kernel_source_sha16") != kernel_source_hash():
+            continue
+        # rocprofv3 prints Itanium-mangled names for the __bf16 instantiations (c++filt cannot demangle
+        # DF16b), e.g. igemm_dma_kernel<__bf16, 2, 4, 4> -> igemm_dma_kernelIDF16bLi2ELi4ELi4EE
+        base, _, targs = kernel.partition("<")
+        frag = base + "I" + "".join("DF16b" if a.strip() == "__bf16" else ("f" if a.strip() == "float" else f"Li{a.strip()}E")
+                                    for a in targs.rstrip(">").split(",")) + "E" if targs else base
+        for sym, v in table.items():
+            if frag in sym or kernel in sym:
+                return v["bytes_corrected"]
     return None
 
 
@@ -147,8 +159,19 @@ def per_layer_table(step, args):
     print(f"sum {sum(v[0] for v in tot.values()):.3f} ms", file=sys.stderr)
 
 
-def cpu_baseline(batch, h, w, cin):
-    """CPU port of the reference path: forward + focal/dice loss + backward on the host cores."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(batch, h, w, cin, iters=3):
+    """CPU port of the reference path: forward + focal/dice loss + backward on the host cores (one warm-up,
+    >= 3 timed iterations, median, core count and CPU model stated)."""
     from oracle import unetdc_torch_cpu as otc
     from models.model_2 import UNetDC
     torch.manual_seed(0)
@@ -159,12 +182,143 @@ def cpu_baseline(batch, h, w, cin):
     xw, tw = synthetic_batch(99, 1, h, w, cin, discs=20)
     otc.train_step_grads(xw, tw, sd, dict(model.DILATIONS))          # warm-up (oneDNN primitive caches)
     x, t = synthetic_batch(100, batch, h, w, cin, discs=50)
-    t0 = time.perf_counter()
-    otc.train_step_grads(x, t, sd, dict(model.DILATIONS))
-    dt = time.perf_counter() - t0
+    times = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        otc.train_step_grads(x, t, {k: v.clone() for k, v in sd.items()}, dict(model.DILATIONS))
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[len(times) // 2]
     return {"value": batch / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 fwd+loss+bwd step of bs={batch} {h}x{w}x{cin} fp32 on PyTorch-CPU "
-                      f"(oracle/unetdc_torch_cpu.py) after a bs=1 warm-up; {dt:.1f} s"}
+            "cpu_model": cpu_model_name(),
+            "sample": f"median of {iters} fwd+loss+bwd steps of bs={batch} {h}x{w}x{cin} fp32 on PyTorch-CPU "
+                      f"(oracle/unetdc_torch_cpu.py) after a bs=1 warm-up; step times "
+                      + "/".join(f"{v:.1f}" for v in times) + " s"}
+
+
+def kernel_source_hash():
+    """sha256 over the HIP sources the shared library is built from: stamps profiles/*_pmc_traffic.json so that a
+    traffic figure measured on OTHER kernels is never reported for these."""
+    import hashlib
+    from unet_dc_segmentation_amd import build as b
+    h = hashlib.sha256()
+    for f in sorted(b.SOURCES + b.HEADERS):
+        with open(os.path.join(b.CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def executed_fraction(a, name):
+    """Fraction of the nominal taps the LDS-DMA conv kernel executes: a 256-pixel block of the flattened map skips a
+    tap when no pixel of the block can reach the image through it (block-level tap skipping, igemm_dma16.hip);
+    d = 16 on a 32 x 32 map executes 6 of 9 taps (an 8-row block reaches the image through the centre row of taps and
+    one of the two outer rows; 4 of 9 tap-pixel pairs are in bounds).  1.0 for transposed convs and the halo-patch kernel."""
+    if "convT" in name:
+        return 1.0
+    if name == "unetdc_conv3x3_fwd":
+        n, h, w, d = a[9], a[10], a[11], a[14]
+    elif name == "unetdc_conv3x3_dgrad":
+        n, h, w, d = a[5], a[6], a[7], a[10]
+    elif name == "unetdc_conv3x3_dgrad_bnstats":
+        n, h, w, d = a[14], a[15], a[16], a[19]
+    elif name == "unetdc_conv3x3_dgrad_colsum":
+        n, h, w, d = a[10], a[11], a[12], a[15]
+    else:
+        return 1.0
+    bm, live, total = 256, 0, 0
+    for m0 in range(0, h * w, bm):                        # blocks never straddle images when h*w % 256 == 0
+        m1 = min(m0 + bm, h * w) - 1
+        y0, x0, y1, x1 = m0 // w, m0 % w, m1 // w, m1 % w
+        bx0, bx1 = (x0, x1) if y0 == y1 else (0, w - 1)
+        for t in range(9):
+            dy, dx = (t // 3 - 1) * d, (t % 3 - 1) * d
+            total += 1
+            if y1 + dy >= 0 and y0 + dy < h and bx1 + dx >= 0 and bx0 + dx < w:
+                live += 1
+    return live / total if (h * w) % bm == 0 else 1.0
+
+
+def hbm_bytes(name, a, es):
+    """Algorithmic bytes of one launch of an HBM-bound entry point (each operand read or written once)."""
+    if name == "unetdc_bn_relu_apply":                     # y -> a (+ pooled)
+        n, h, w, c = a[8:12]
+        return n * h * w * c * es * (2 + (0.25 if a[6] else 0))
+    if name == "unetdc_bn_relu_bwd":                       # dskip (+ dpool) + y -> dy
+        n, h, w, c = a[20:24]
+        return n * h * w * c * es * ((1 if a[0] else 0) + (0.25 if a[2] else 0) + 2)
+    if name == "unetdc_head_fwd":                          # a -> probs (fp32)
+        n, h, w, c, oc = a[5:10]
+        return n * h * w * (c * es + oc * 4)
+    if name == "unetdc_head_bwd":                          # dprobs, probs, a -> da
+        n, h, w, c, oc = a[11:16]
+        return n * h * w * (2 * c * es + 2 * oc * 4)
+    if name == "unetdc_conv3x3_first_fwd":                 # x (fp32 NCHW) -> y
+        n, h, w, cin, cout = a[8:13]
+        return n * h * w * (cin * 4 + cout * es)
+    if name == "unetdc_conv3x3_first_wgrad":               # x, dy -> dW
+        n, h, w, cin, cout = a[6:11]
+        return n * h * w * (cin * 4 + cout * es)
+    raise KeyError(name)
+
+
+HBM_CALLS = ["unetdc_bn_relu_apply", "unetdc_bn_relu_bwd", "unetdc_head_fwd", "unetdc_head_bwd",
+             "unetdc_conv3x3_first_fwd", "unetdc_conv3x3_first_wgrad"]
+
+
+def hbm_leg(step, es, nsteps=3):
+    """Instrumented pass (separate from the timed region): per HBM-bound entry point, GB/s vs the 8 TB/s peak."""
+    from unet_dc_segmentation_amd import _lib
+    _lib.start_timing(HBM_CALLS)
+    for _ in range(nsteps):
+        step()
+    rec = _lib.stop_timing()
+    agg = {}
+    for tagged, a, ms in rec:
+        name = tagged.split("|")[0]
+        g = agg.setdefault(name, [0.0, 0.0, 0])
+        g[0] += hbm_bytes(name, a, es)
+        g[1] += ms
+        g[2] += 1
+    rows = []
+    for name, (nbytes, ms, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        rows.append({"entry": name, "launches_per_step": cnt / nsteps, "ms_per_step": ms / nsteps,
+                     "algorithmic_GB_per_step": nbytes / nsteps / 1e9, "achieved_GBps": gbs, "frac": gbs / PEAK_HBM_GBS})
+    tot_b, tot_ms = sum(v[0] for v in agg.values()), sum(v[1] for v in agg.values())
+    return {"bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s", "achieved": tot_b / (tot_ms * 1e-3) / 1e9 if tot_ms else None,
+            "frac": tot_b / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if tot_ms else None, "ms_per_step": tot_ms / nsteps,
+            "measured": f"HIP events around each call, {nsteps} instrumented steps after the timed region", "entries": rows}
+
+
+def self_launch(args, argv):
+    """--gpus N without a torchrun environment: become the launcher.  Nothing here touches HIP (device_count() reads
+    sysfs on this image); the children are fresh processes, never an exec of an initialised one."""
+    import socket
+    import subprocess
+    n = args.gpus
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"[bench] --gpus {n} requested but this host exposes {have} GPU(s): refusing to report a {have}-GPU "
+              f"number as a {n}-GPU one", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if any(rcs):
+        print(f"[bench] rank exit codes {rcs}: failing", file=sys.stderr)
+        sys.stdout.write(out0 or "")
+        return 1
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return 0
 
 
 def main():
@@ -184,6 +338,8 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
                     help="train = the headline metric (default); infer = forward-only eval (BASELINE configs[1])")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
 
     from unet_dc_segmentation_amd import _lib, dp as dpmod
     from utils.metrics_DC import focal_dice_loss
@@ -193,8 +349,8 @@ def main():
     rank, local, world = dpmod.init_from_env(backend)
     if "UNETDC_BENCH_DEVICE" in os.environ:
         local = int(os.environ["UNETDC_BENCH_DEVICE"])
-    if world != args.gpus and rank == 0:
-        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: refusing to mislabel the run")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -254,6 +410,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     final_loss = float(loss.item())
+    hbm = hbm_leg(step, 2 if args.dtype == "bf16" else 4) if args.mode == "train" else None
 
     if rank == 0:
         # ---- roofline of the dominant kernel -------------------------------------------------
@@ -261,16 +418,18 @@ def main():
         for tagged, a, ms in records:
             name, key = tagged.split("|")              # C-ABI entry point | dispatched kernel symbol
             fl, nbytes = igemm_flops(name, a, 2 if args.dtype == "bf16" else 4)
-            gsum = groups.setdefault(key, [0.0, 0.0, 0, 0.0])
+            gsum = groups.setdefault(key, [0.0, 0.0, 0, 0.0, 0.0])
             gsum[0] += fl
             gsum[1] += ms
             gsum[2] += 1
             gsum[3] += nbytes
+            gsum[4] += fl * (executed_fraction(a, name) if "dma" in key else 1.0)
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         kernels = []
-        for key, (fl, ms, cnt, nbytes) in groups.items():
+        for key, (fl, ms, cnt, nbytes, flx) in groups.items():
             kernels.append({"kernel": key, "launches_per_step": cnt / args.steps, "avg_launch_ms": ms / cnt,
                             "gflop_per_launch": fl / cnt / 1e9, "tflops": fl / (ms * 1e-3) / 1e12,
+                            "executed_gflop_per_launch": flx / cnt / 1e9, "tflops_executed": flx / (ms * 1e-3) / 1e12,
                             "ms_per_step": ms / args.steps, "algorithmic_bytes_per_launch": nbytes / cnt})
         kernels.sort(key=lambda k: -k["ms_per_step"])
         dom = kernels[0]
@@ -278,14 +437,20 @@ def main():
                     "unit": "TFLOP/s", "frac": dom["tflops"] / peak,
                     "traffic": pmc_traffic(dom["kernel"]) if args.mode == "train" and args.dtype == "bf16" else None,
                     "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
-                    "flop_per_launch": dom["gflop_per_launch"] * 1e9, "avg_launch_ms": dom["avg_launch_ms"],
+                    "flop_per_launch": dom["gflop_per_launch"] * 1e9,
+                    "executed_flop_per_launch": dom["executed_gflop_per_launch"] * 1e9,
+                    "flop_note": "nominal dense FLOPs, padded taps included (SURVEY 8d); executed = after block-level "
+                                 "skipping of taps that cannot reach the image",
+                    "avg_launch_ms": dom["avg_launch_ms"],
                     "launches_per_step": dom["launches_per_step"], "all_igemm_kernels": kernels}
         nominal_gflop_img = ((1153.9 if args.mode == "train" else 384.74)
                              if (args.size == 512 and args.in_channels == 1) else None)
         imgs = args.batch * world * args.steps
         out = {
-            "metric": "images/sec fwd+bwd, 512x512x1 U-Net-DC, bs=8/GPU" if args.mode == "train"
-                      else "images/sec forward-only inference, 512x512x1 U-Net-DC, bs=8/GPU",
+            "metric": (f"images/sec fwd+bwd, {args.size}x{args.size}x{args.in_channels} "
+                       f"{'U-Net-DC' if args.arch == 'unetdc' else 'U-Net'}, bs={args.batch}/GPU") if args.mode == "train"
+                      else (f"images/sec forward-only inference, {args.size}x{args.size}x{args.in_channels} "
+                            f"{'U-Net-DC' if args.arch == 'unetdc' else 'U-Net'}, bs={args.batch}/GPU"),
             "value": imgs / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -298,12 +463,15 @@ def main():
                        "timed_region": "zero_grad, model(x), focal_dice_loss, backward, all-reduce, Adam step, weight re-pack"
                                        if args.mode == "train" else "model(x) under no_grad + threshold, input resident in HBM"},
             "roofline": roofline,
+            "hbm_leg": hbm,
             "final_value": final_loss,
         }
         if nominal_gflop_img:
             out["whole_step_tflops_nominal"] = nominal_gflop_img * 1e9 * imgs / elapsed / 1e12
         if wrapper is not None:
-            out["allreduce_buckets_per_step"] = wrapper.stats["buckets"] / (args.steps + args.warmup)
+            out["allreduce_buckets_per_step"] = wrapper.stats["buckets"] / max(wrapper.stats["steps"], 1)
+            out["collective"] = {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "ranks": world,
+                                 "payload_MB_per_step": wrapper.stats["elems"] * 4 / max(wrapper.stats["steps"], 1) / 1e6}
         if world == 1 and not args.no_cpu_baseline and args.mode == "train":
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.size, args.size, args.in_channels)
         print(json.dumps(out), flush=True)

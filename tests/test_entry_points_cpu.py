@@ -170,3 +170,38 @@ def test_dataset_transform_conventions_and_worker_seeding(tmp_path):
     e2 = torch.cat(list(loader))
     assert not torch.equal(e1[0], e1[1])                  # worker 0 and worker 1 differ
     assert not torch.equal(e1, e2)                        # the next epoch does not replay the sequence
+
+
+def test_bench_gpus_flag_never_mislabels_a_run():
+    """`python bench.py --gpus N` without a torchrun environment launches its own ranks -- and refuses (non-zero exit,
+    nothing on stdout) when the host has fewer than N GPUs, instead of reporting a one-rank number as an N-GPU one;
+    under a torchrun environment a WORLD_SIZE that contradicts --gpus is refused as well."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    n = torch.cuda.device_count() + 1 if torch.cuda.device_count() else 2
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(max(n, 2)), "--steps", "1",
+                        "--warmup", "0"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == "" and "refusing" in r.stderr
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == "" and "refusing to mislabel" in r.stderr
+
+
+def test_bench_roofline_bookkeeping():
+    """Executed-vs-nominal FLOPs (block-level tap skipping: d = 16 on a 32 x 32 map keeps 6 of 9 taps per 8-row block), algorithmic bytes
+    of the HBM-bound entry points, and the kernel-source stamp of the PMC traffic file."""
+    import bench
+    fwd = lambda n, h, w, cin, cout, d: (0, cin, 0, 0, None, None, 0, cout, 0, n, h, w, cin, cout, d, 1, 0)   # noqa: E731
+    assert abs(bench.executed_fraction(fwd(8, 32, 32, 1024, 1024, 16), "unetdc_conv3x3_fwd") - 6 / 9) < 1e-12
+    assert bench.executed_fraction(fwd(8, 64, 64, 512, 512, 1), "unetdc_conv3x3_fwd") == 1.0
+    f8 = bench.executed_fraction(fwd(8, 64, 64, 512, 512, 8), "unetdc_conv3x3_fwd")
+    assert 0.7 < f8 < 1.0                                    # d = 8 on 64 x 64: edge blocks lose their outer taps
+    fl, nbytes = bench.igemm_flops("unetdc_conv3x3_fwd", fwd(8, 64, 64, 512, 512, 1))
+    assert fl == 2.0 * 8 * 64 * 64 * 512 * 512 * 9 and nbytes == (8 * 64 * 64 * 1024 + 9 * 512 * 512) * 2
+    apply_args = (1, 64, 1, 1, 1, 64, 1, 64, 8, 512, 512, 64, 1, 0)
+    assert bench.hbm_bytes("unetdc_bn_relu_apply", apply_args, 2) == 8 * 512 * 512 * 64 * 2 * 2.25
+    h1, h2 = bench.kernel_source_hash(), bench.kernel_source_hash()
+    assert h1 == h2 and len(h1) == 16

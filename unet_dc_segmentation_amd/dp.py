@@ -39,7 +39,7 @@ class DataParallel:
         self._works = []
         self._pending = None            # (flat, lo, hi) not yet launched
         self._flat = None
-        self.stats = {"buckets": 0, "elems": 0}
+        self.stats = {"buckets": 0, "elems": 0, "steps": 0}
         if broadcast:
             self.broadcast_state()
         model.grad_ready_hook = self._on_ready
@@ -95,6 +95,7 @@ class DataParallel:
             if view is not None:
                 view.div_(self.world)
         self._works.clear()
+        self.stats["steps"] += 1
 
     # -------------------------------------------------------------- fallback for the ATen-CPU path
     def sync_gradients(self):
