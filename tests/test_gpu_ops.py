@@ -44,6 +44,12 @@ CONV_CASES = [  # n, h, w, cin, cout, d
     (1, 264, 512, 128, 64, 1),   # two K chunks through a single patch buffer; H not a power of two
     (2, 256, 256, 64, 128, 2),   # 8-wave config, d = 2
     (1, 512, 256, 128, 128, 2),  # 8-wave config, two K chunks, double-buffered patch
+    # bf16: persistent lattice-halo kernel (igemm_lattice.hip) -- several items per workgroup, n-blocks, dilation as lattice stride
+    (3, 512, 256, 64, 64, 1),    # 1536 tiles on 512 workgroups: three items each through ONE patch buffer
+    (4, 128, 128, 128, 256, 1),  # BN = 128, two n-blocks (constants reloaded per item), two K chunks, two items per workgroup
+    (2, 128, 128, 256, 128, 4),  # d = 4: sixteen 32 x 32 sub-lattices per image, four K chunks
+    (1, 64, 256, 64, 64, 2),     # d = 2 with the 4-wave configuration, fewer items than workgroups
+    (1, 1024, 64, 64, 128, 1),   # tall narrow map: two tiles per row
 ]
 
 
@@ -338,7 +344,8 @@ def test_pack_many_matches_per_layer_packers():
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("case", [(2, 16, 24, 64, 64, 1), (1, 32, 32, 128, 256, 4), (2, 256, 256, 64, 64, 1),
-                                  (1, 512, 256, 128, 64, 2), (2, 96, 160, 64, 64, 1), (2, 48, 80, 128, 128, 1)])
+                                  (1, 512, 256, 128, 64, 2), (2, 96, 160, 64, 64, 1), (2, 48, 80, 128, 128, 1),
+                                  (2, 128, 128, 256, 128, 1), (3, 512, 256, 64, 64, 1), (1, 128, 128, 128, 128, 4)])
 def test_dgrad_with_fused_bn_backward_statistics(dtype, case):
     """conv dgrad whose epilogue also emits the BatchNorm-backward partial sums of the consuming stage
     (S1 = sum dx*[n>0], S2 = sum dx*[n>0]*xhat), and bn_relu_bwd consuming them instead of its own pass."""

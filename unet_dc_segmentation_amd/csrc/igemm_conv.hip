@@ -345,6 +345,7 @@ int launch_igemm(IgemmParams& p, int dtype, hipStream_t stream) {
     p.wo_shift = p2 ? __builtin_ctz((unsigned)p.Wo) : -1;
     p.howo_shift = p2 ? __builtin_ctzl((unsigned long)howo) : -1;
   }
+  if (igemm_choice() == 0 && igemm_lattice_supported(p, dtype)) return launch_igemm_lattice(p, stream);
   if (igemm_choice() == 0 && igemm_halo_supported(p, dtype)) return launch_igemm_halo(p, dtype, stream);
   if (!use_legacy() && igemm_dma_supported(p, dtype)) return launch_igemm_dma(p, dtype, stream);
   if (p.mode == MODE_BNBWD) return UNETDC_EUNSUPPORTED;      // first-generation kernel: caller reduces separately

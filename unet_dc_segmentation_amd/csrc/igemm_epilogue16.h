@@ -20,25 +20,37 @@ __device__ __forceinline__ void unpack4_bf16(const u32x2& r, float (&t)[4]) {
   t[2] = bits_f32(u1 << 16); t[3] = bits_f32(u1 & 0xffff0000u);
 }
 
-// TMT M-tiles of 16 rows x 4 N-tiles of 16 channels per wave -> global memory (bf16)
-template <int MODE, int TMT>
-__device__ __forceinline__ void epilogue16(const IgemmParams& p, f32x4 (&acc)[TMT][4], const bool (&tile_ok)[TMT],
-                                           const unsigned (&voff)[TMT], unsigned row_bytes, const unsigned (&yoff)[TMT],
-                                           unsigned yrow_bytes, int ccol, float (&s)[4], float (&q)[4]) {
-  const __amdgpu_buffer_rsrc_t orr = whole_buffer(p.out);
-  const __amdgpu_buffer_rsrc_t yrr = whole_buffer(MODE == MODE_BNBWD ? p.bn_y : p.out);
-  float k0[4] = {0.f, 0.f, 0.f, 0.f}, k1[4] = {0.f, 0.f, 0.f, 0.f}, mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f};
+// per-channel constants of the four channels a lane owns (bias | scale, shift | + mean, rstd)
+struct Epi16Consts {
+  float k0[4], k1[4], mu[4], rs[4];
+};
+template <int MODE>
+__device__ __forceinline__ Epi16Consts epi16_consts(const IgemmParams& p, int ccol) {
+  Epi16Consts c;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { c.k0[k] = 0.f; c.k1[k] = 0.f; c.mu[k] = 0.f; c.rs[k] = 0.f; }
   if (MODE == MODE_AFFINE_RELU || MODE == MODE_BNBWD) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { k0[k] = p.scale[ccol + k]; k1[k] = p.shift[ccol + k]; }
+    for (int k = 0; k < 4; ++k) { c.k0[k] = p.scale[ccol + k]; c.k1[k] = p.shift[ccol + k]; }
   } else if (p.bias) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) k1[k] = p.bias[ccol + k];
+    for (int k = 0; k < 4; ++k) c.k1[k] = p.bias[ccol + k];
   }
   if (MODE == MODE_BNBWD) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { mu[k] = p.bn_mean[ccol + k]; rs[k] = p.bn_rstd[ccol + k]; }
+    for (int k = 0; k < 4; ++k) { c.mu[k] = p.bn_mean[ccol + k]; c.rs[k] = p.bn_rstd[ccol + k]; }
   }
+  return c;
+}
+
+// TMT M-tiles of 16 rows x 4 N-tiles of 16 channels per wave -> global memory (bf16); constants preloaded
+template <int MODE, int TMT>
+__device__ __forceinline__ void epilogue16c(const IgemmParams& p, f32x4 (&acc)[TMT][4], const bool (&tile_ok)[TMT],
+                                            const unsigned (&voff)[TMT], unsigned row_bytes, const unsigned (&yoff)[TMT],
+                                            unsigned yrow_bytes, const Epi16Consts& kc, float (&s)[4], float (&q)[4]) {
+  const __amdgpu_buffer_rsrc_t orr = whole_buffer(p.out);
+  const __amdgpu_buffer_rsrc_t yrr = whole_buffer(MODE == MODE_BNBWD ? p.bn_y : p.out);
+  const float (&k0)[4] = kc.k0, (&k1)[4] = kc.k1, (&mu)[4] = kc.mu, (&rs)[4] = kc.rs;
   constexpr int GRP = TMT < 4 ? TMT : 4;                  // tiles whose saved-output loads are in flight together
 #pragma unroll
   for (int i0 = 0; i0 < TMT; i0 += GRP) {
@@ -88,6 +100,15 @@ __device__ __forceinline__ void epilogue16(const IgemmParams& p, f32x4 (&acc)[TM
       }
     }
   }
+}
+
+// same, loading the per-channel constants first (one call per workgroup in the non-persistent kernels)
+template <int MODE, int TMT>
+__device__ __forceinline__ void epilogue16(const IgemmParams& p, f32x4 (&acc)[TMT][4], const bool (&tile_ok)[TMT],
+                                           const unsigned (&voff)[TMT], unsigned row_bytes, const unsigned (&yoff)[TMT],
+                                           unsigned yrow_bytes, int ccol, float (&s)[4], float (&q)[4]) {
+  const Epi16Consts kc = epi16_consts<MODE>(p, ccol);
+  epilogue16c<MODE, TMT>(p, acc, tile_ok, voff, row_bytes, yoff, yrow_bytes, kc, s, q);
 }
 
 // per-channel statistics of a workgroup (WM x WN waves) -> one partial row; red = LDS scratch of NW*128 floats

@@ -1,0 +1,418 @@
+// Lattice-halo implicit GEMM (bf16): dilated 3x3 convolution forward / dgrad, persistent workgroups.
+//
+//   out[n, Y, X, co] = sum_{ky,kx,ci} x[n, Y + (ky-1) d, X + (kx-1) d, ci] * w[ky*3+kx][co][ci]     (models/model_2.py:41-51)
+//
+// What round 1's kernels left on the table (SQ counters, profiles/r02_sq_baseline.json):
+//   * the per-tap LDS-DMA kernel (igemm_dma16) stages 64 KB per 256x256x64 step, i.e. ~65 GB/s per CU at full MFMA rate --
+//     the rate at which a CU can pull bytes from L2 into LDS at all (MI355X_MICROARCH.md, gather into LDS: 66-73 GB/s/CU);
+//   * the halo-patch kernel (igemm_halo16) staged the input once per 9 taps but spent 5 VALU instructions per MFMA on
+//     fragment addresses (VALU-bound), lost 24 % of its LDS cycles to bank conflicts of the x-shifted taps, drained the VM
+//     counter at every tap and paid a full prologue + epilogue per 256-pixel tile (MFMA pipe 35 % busy).
+// This kernel keeps the halo patch and removes those costs:
+//   * DILATION LIVES IN THE GLOBAL ADDRESSES ONLY.  A d-dilated 3x3 conv is d*d independent dense 3x3 convs on the
+//     sub-lattices x[py::d, px::d]; a workgroup owns an 8 x 32 tile of ONE sub-lattice and gathers its (8+2) x (32+2)
+//     patch with stride d (LDS-DMA takes a per-lane source address; every pixel is a whole 128-byte line).  In LDS every
+//     layer is a dense conv with halo 1: tap (ky, kx) reads patch rows shifted by ky, kx.
+//   * NO ADDRESS ARITHMETIC IN THE TAP LOOP: the 9 taps are unrolled; a fragment read is `ds_read_b128 v, vbase offset:imm`
+//     with 6 + 2 per-lane bases computed once; everything tap-dependent on the global side is a scalar offset (soffset).
+//   * CONFLICT-FREE SHIFTED READS: the 16 rows of an MFMA tile are consecutive patch pixels starting at ANY column, and
+//     ds_read_b128 serves lanes {0-3,12-15 | rb} and {4-11 | rb^1} in one pass; lanes 0-3,12-15 read the even pixels and
+//     lanes 4-11 the odd ones (a permutation of the tile's rows, undone by the store addresses), the XOR key is a function
+//     of the patch column: the two lane sets always sit in different 128-byte halves of the bank row, whatever the shift.
+//   * COUNTED WAITS: weights travel through a 3-stage ring two taps ahead, the next patch (next K chunk or next tile) is
+//     fetched in slices during the first taps; DMAs are issued from inline asm (lds_dma.h) so that neither
+//     __syncthreads() nor the compiler's LDS-alias rule drains the VM counter; one raw s_barrier per tap.
+//   * PERSISTENT: a workgroup walks a list of (tile, n-block) items; the pipeline runs across item boundaries (the next
+//     item's patch and first weights are in flight during the epilogue stores of the current one).
+//
+// Tiles: 256 pixels x BN channels, waves WM x WN, a wave owns MT M-tiles of 16 pixels x 64 channels
+//   BN = 64 : 4 waves (4 x 1), MT = 4, ONE patch buffer (2 workgroups per CU hide the reload)
+//   BN = 128: 8 waves (4 x 2), MT = 4, two patch buffers
+// LDS: [NPB patch buffers][3 weight stages of BN x 128 B][statistics scratch].
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "igemm_epilogue16.h"
+#include "kernels.h"
+#include "lds_dma.h"
+
+namespace unetdc {
+
+constexpr int LTH = 8, LTW = 32;                  // lattice tile
+constexpr int LPH = LTH + 2, LPW = LTW + 2;       // patch (halo 1)
+constexpr int LPP = LPH * LPW;                    // 340 patch pixels
+constexpr int LPI = (LPP + 7) / 8;                // 43 DMA wave-instructions (8 pixel rows of 128 B each)
+constexpr unsigned LOOB = 0x80000000u;
+
+struct LatticeParams {
+  int d;                      // dilation = lattice stride
+  int Hs, Ws;                 // lattice size H / d, W / d
+  int tiles_x, tiles_y;       // Ws / 32, Hs / 8
+  int tiles_per_img;          // d * d * tiles_x * tiles_y
+  int nblocks;                // Cout / BN
+  int items;                  // N * tiles_per_img * nblocks
+  int nkc;                    // Cin / 64
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// patch slices issued at tap t: PJ slices in groups of SPT over the first taps
+template <int PJ, int SPT> __device__ constexpr int lat_nsl(int t) {
+  return t < 0 ? 0 : ((PJ - t * SPT) <= 0 ? 0 : ((PJ - t * SPT) < SPT ? (PJ - t * SPT) : SPT));
+}
+#endif
+
+template <int WM, int WN, int MT, int NPB, int MODE>
+__global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const IgemmParams p, const LatticeParams q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NW = WM * WN, BN = WN * 64;
+  constexpr int BI = BN / 8 / NW;                 // weight DMA instructions per wave per tap
+  constexpr int PJ = (LPI + NW - 1) / NW;         // patch DMA instructions per wave per chunk (uniform: padded)
+  constexpr int SPT = (NW == 4) ? 3 : 2;          // patch slices per tap while prefetching
+  constexpr int PBUF = PJ * NW * 1024;            // bytes per patch buffer
+  constexpr int WST = BN * 128;                   // bytes per weight stage
+  constexpr int OFF_W = NPB * PBUF, OFF_RED = OFF_W + 3 * WST;
+  constexpr int NST = MT * 4;                     // epilogue stores per wave and tile
+  static_assert(WM * MT == 16 && (MT % 2) == 0, "a workgroup owns 16 M-tiles = 8 rows x 32 pixels");
+  static_assert(BN % (8 * NW) == 0, "weight rows / wave mismatch");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const unsigned lds_base = lds_addr_of(smem);
+  const int G = gridDim.x;
+  const int d = q.d;
+
+  const unsigned xbytes = (unsigned)((long)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.ldx * 2);
+  const unsigned wbytes = (unsigned)((long)9 * p.Cout * p.Cin * 2);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, wbytes, 0x00020000);
+
+  // ---- per-lane constants --------------------------------------------------------------------------------------
+  const int sub = lane >> 3, pc = lane & 7;
+  // patch slice sl of this wave = DMA instruction wave + NW*sl = patch pixels 8*instr .. 8*instr+7 (row-major in the
+  // 10 x 34 patch); this lane feeds pixel pr, physical chunk pc <- logical chunk pc ^ key(column)
+  unsigned prc[PJ];                               // ppy | ppx << 8 | chunk byte offset << 16 | invalid << 31
+#pragma unroll
+  for (int sl = 0; sl < PJ; ++sl) {
+    const int pr = (wave + NW * sl) * 8 + sub;
+    const int ppy = (pr * 1928) >> 16, ppx = pr - ppy * LPW;       // pr / 34 for pr < 1024
+    const int ch = pc ^ ((ppx >> 1) & 7);
+    prc[sl] = (unsigned)ppy | ((unsigned)ppx << 8) | ((unsigned)(ch * 16) << 16) | (pr < LPP ? 0u : 0x80000000u);
+  }
+  // weight rows: LDS row lrow of the stage = N tile (q >> 4) of its 64-channel group, column q & 15
+  //   <-> output channel 4*(q & 15) + (q >> 4): the four N tiles of a lane hold four consecutive channels
+  unsigned bbase[BI];
+#pragma unroll
+  for (int j = 0; j < BI; ++j) {
+    const int lrow = (wave + NW * j) * 8 + sub;
+    const int grp = lrow >> 6, qq = lrow & 63;
+    const int cc = (qq & 15) * 4 + (qq >> 4);
+    const int c = pc ^ ((lrow >> 1) & 7);
+    bbase[j] = (unsigned)((grp * 64 + cc) * p.Cin * 2 + c * 16);
+  }
+  // fragment read bases.  MFMA row m of a tile (supplied by lanes with c16 = m) is pixel PI(m) of the 16:
+  // lanes 0-3,12-15 -> even pixels, lanes 4-11 -> odd pixels
+  const int c16 = lane & 15, rb = lane >> 4;
+  const int pi = (c16 < 4) ? 2 * c16 : (c16 < 12 ? 2 * (c16 - 4) + 1 : 2 * (c16 - 8));
+  int aoff[3][2], boff[2];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int px = kx + pi;                     // patch column (mod 16: +16 for the right half keeps the key)
+      aoff[kx][g] = (wm * (MT / 2) * LPW + px) * 128 + (((4 * g + rb) ^ ((px >> 1) & 7)) << 4);
+    }
+#pragma unroll
+  for (int g = 0; g < 2; ++g) boff[g] = OFF_W + (wn * 64 + c16) * 128 + (((4 * g + rb) ^ ((c16 >> 1) & 7)) << 4);
+
+  // ---- work items ---------------------------------------------------------------------------------------------------
+  struct Item { int img, phy, phx, ly0, lx0, nblk, mtile; };
+  auto decode = [&](int item) {
+    Item it;
+    it.nblk = item % q.nblocks;
+    it.mtile = item / q.nblocks;
+    it.img = it.mtile / q.tiles_per_img;
+    int r = it.mtile - it.img * q.tiles_per_img;
+    const int tpp = q.tiles_x * q.tiles_y;        // tiles per phase
+    const int ph = r / tpp;
+    r -= ph * tpp;
+    it.phy = ph / d;
+    it.phx = ph - it.phy * d;
+    const int ty = r / q.tiles_x;
+    it.ly0 = ty * LTH;
+    it.lx0 = (r - ty * q.tiles_x) * LTW;
+    return it;
+  };
+  const int first = xcd_remap(blockIdx.x, G);
+  if (first >= q.items) return;                   // (grid <= items: never taken)
+
+  // ---- DMA issue -----------------------------------------------------------------------------------------------------
+  auto issue_slice = [&](int sl, int buf, const Item& it, int kc, bool valid) {
+    const unsigned pk = prc[sl];
+    const int ly = it.ly0 - 1 + (int)(pk & 0xffu), lx = it.lx0 - 1 + (int)((pk >> 8) & 0xffu);
+    const bool ok = valid && (int)pk >= 0 && (unsigned)ly < (unsigned)q.Hs && (unsigned)lx < (unsigned)q.Ws;
+    const int Y = ly * d + it.phy, X = lx * d + it.phx;
+    const unsigned voff = ok ? (unsigned)((Y * p.Wi + X) * p.ldx * 2) + ((pk >> 16) & 0xffu) : LOOB;
+    const unsigned soff = (unsigned)(it.img * p.Hi * p.Wi * p.ldx * 2 + kc * 128);
+    lds_dma16(xr, lds_base + buf * PBUF + (wave + NW * sl) * 1024, voff, soff);
+  };
+  auto issue_w = [&](int stage, int tap, int kc, int nblk, bool valid) {
+    const unsigned soff = (unsigned)(((tap * p.Cout + nblk * BN) * p.Cin + kc * 64) * 2);
+#pragma unroll
+    for (int j = 0; j < BI; ++j)
+      lds_dma16(wr, lds_base + OFF_W + stage * WST + (wave + NW * j) * 1024, valid ? bbase[j] : LOOB, soff);
+  };
+
+  f32x4 acc[MT][4];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+  };
+  zero_acc();
+
+  // one tap: fragments of both 32-channel halves, MT*4*2 MFMAs
+  auto compute_tap = [&](int ky, int kx, int stage, const int (&ab)[3][2]) {
+    u32x4 fa[2][MT], fb[2][4];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[g][j] = ld16(smem + boff[g] + stage * WST + j * 16 * 128);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        fa[g][i] = ld16(smem + ab[kx][g] + ((i >> 1) + ky) * (LPW * 128) + (i & 1) * (16 * 128));
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[g][i]),
+                                                              __builtin_bit_cast(bf16x8, fb[g][j]), acc[i][j], 0, 0, 0);
+  };
+
+  // ---- epilogue of one item -----------------------------------------------------------------------------------------------
+  const unsigned ldob = (unsigned)(p.ldo * 2), ldyb = (unsigned)(p.bn_ldy * 2);
+  const int xb = (rb == 0) ? 0 : (rb == 1 ? 1 : (rb == 2 ? 9 : 8));          // pixel of accumulator row 4*rb + v = xb + 2v
+  Epi16Consts ec;
+  auto load_consts = [&](int nblk) { ec = epi16_consts<MODE>(p, nblk * BN + wn * 64 + 4 * c16); };
+  auto epilogue = [&](const Item& it) {
+    bool tile_ok[MT];
+    unsigned voff[MT], yoff[MT];
+    const int col = it.nblk * BN + wn * 64 + 4 * c16;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int gm = wm * MT + i;                                            // M tile of the workgroup: row gm >> 1, half gm & 1
+      const int Y = (it.ly0 + (gm >> 1)) * d + it.phy, X = (it.lx0 + 16 * (gm & 1) + xb) * d + it.phx;
+      const unsigned pix = (unsigned)((it.img * p.Ho + Y) * p.Wo + X);
+      tile_ok[i] = true;
+      voff[i] = pix * ldob + (unsigned)(col * 2);
+      yoff[i] = pix * ldyb + (unsigned)(col * 2);
+    }
+    float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+    const unsigned rbytes = 2u * (unsigned)d * ldob, yrbytes = 2u * (unsigned)d * ldyb;   // accumulator rows are 2 lattice pixels apart
+    epilogue16c<MODE, MT>(p, acc, tile_ok, voff, rbytes, yoff, yrbytes, ec, s4, q4);
+    if (MODE == MODE_STATS || MODE == MODE_BNBWD) {
+      // one partial row per tile (same row count and layout as the other conv kernels); scratch of its own: the stage
+      // and patch buffers carry the next item's prefetch.  The >= 9 tap barriers between two tiles order the reuse.
+      constexpr int nrow = (MODE == MODE_BNBWD) ? 3 : 2;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        s4[k] += __shfl_xor(s4[k], 16, 64); q4[k] += __shfl_xor(q4[k], 16, 64);
+        s4[k] += __shfl_xor(s4[k], 32, 64); q4[k] += __shfl_xor(q4[k], 32, 64);
+      }
+      float* red = reinterpret_cast<float*>(smem + OFF_RED);                 // [wave][4 k][2][16 c]
+      if (rb == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          red[((wave * 4 + k) * 2 + 0) * 16 + c16] = s4[k];
+          red[((wave * 4 + k) * 2 + 1) * 16 + c16] = q4[k];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      raw_barrier();
+      if (tid < BN) {
+        const int wn2 = tid >> 6, cc = tid & 63, c2 = cc >> 2, k = cc & 3;
+        float su = 0.f, sq = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < WM; ++w2) {
+          su += red[(((w2 * WN + wn2) * 4 + k) * 2 + 0) * 16 + c2];
+          sq += red[(((w2 * WN + wn2) * 4 + k) * 2 + 1) * 16 + c2];
+        }
+        float* row = p.stats + (long)it.mtile * nrow * p.Cout + it.nblk * BN + tid;
+        row[0] = su;
+        row[p.Cout] = sq;
+        if (nrow == 3) row[2 * p.Cout] = 0.f;
+      }
+    }
+    zero_acc();
+  };
+
+  // ---- the pipeline ----------------------------------------------------------------------------------------------------
+  // flat step q = 9*chunk + tap over all (item, K chunk) pairs of this workgroup; weights of step q live in ring stage
+  // tap % 3 and are issued at step q - 2; the patch of chunk c lives in buffer c % NPB.
+  Item cur = decode(first), nxt = cur;
+  int item = first;
+  load_consts(cur.nblk);
+  {
+    if (NPB == 1) { issue_w(0, 0, 0, cur.nblk, true); issue_w(1, 1, 0, cur.nblk, true); }
+#pragma unroll
+    for (int sl = 0; sl < PJ; ++sl) issue_slice(sl, 0, cur, 0, true);
+    if (NPB == 2) { issue_w(0, 0, 0, cur.nblk, true); issue_w(1, 1, 0, cur.nblk, true); }
+  }
+  int cbuf = 0;
+  bool boundary = false;                          // the previous chunk ended an item: its NST stores are younger than the prefetch
+  for (;;) {
+    for (int kc = 0; kc < q.nkc; ++kc) {
+      const bool last_kc = kc + 1 == q.nkc;
+      const int item_n = last_kc ? item + G : item, kc_n = last_kc ? 0 : kc + 1;
+      const bool have_n = item_n < q.items;
+      if (last_kc) nxt = have_n ? decode(item_n) : cur;
+      Item pn;                                      // whose patch the next chunk needs (wave-uniform selects, no references:
+      pn.img = last_kc ? nxt.img : cur.img;         //  a reference to one of two structs sends both to scratch memory)
+      pn.phy = last_kc ? nxt.phy : cur.phy;
+      pn.phx = last_kc ? nxt.phx : cur.phx;
+      pn.ly0 = last_kc ? nxt.ly0 : cur.ly0;
+      pn.lx0 = last_kc ? nxt.lx0 : cur.lx0;
+      pn.nblk = 0; pn.mtile = 0;
+      int ab[3][2];
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) ab[kx][g] = aoff[kx][g] + (NPB == 2 ? cbuf * PBUF : 0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        // ---- wait for the weights of this step (and, at t = 0, the patch of this chunk) -------------------------------
+        if (NPB == 2) {
+          constexpr int nA = lat_nsl<PJ, SPT>(0);
+          if (t == 0) { if (boundary) wait_vmcnt<BI + NST>(); else wait_vmcnt<BI>(); }
+          else if (t == 1) { if (boundary) wait_vmcnt<BI + nA + NST>(); else wait_vmcnt<BI + nA>(); }
+          else if (t == 2) wait_vmcnt<lat_nsl<PJ, SPT>(0) + BI + lat_nsl<PJ, SPT>(1)>();
+          else if (t == 3) wait_vmcnt<lat_nsl<PJ, SPT>(1) + BI + lat_nsl<PJ, SPT>(2)>();
+          else if (t == 4) wait_vmcnt<lat_nsl<PJ, SPT>(2) + BI + lat_nsl<PJ, SPT>(3)>();
+          else if (t == 5) wait_vmcnt<lat_nsl<PJ, SPT>(3) + BI + lat_nsl<PJ, SPT>(4)>();
+          else if (t == 6) wait_vmcnt<lat_nsl<PJ, SPT>(4) + BI + lat_nsl<PJ, SPT>(5)>();
+          else if (t == 7) wait_vmcnt<lat_nsl<PJ, SPT>(5) + BI + lat_nsl<PJ, SPT>(6)>();
+          else wait_vmcnt<lat_nsl<PJ, SPT>(6) + BI + lat_nsl<PJ, SPT>(7)>();
+        } else {
+          // single patch buffer: the slices of this chunk were issued after the previous chunk's last tap, behind
+          // W(q) and W(q+1) and in front of the epilogue stores
+          if (t == 0) { if (boundary) wait_vmcnt<NST>(); else wait_vmcnt<0>(); }
+          else wait_vmcnt<BI>();
+        }
+        raw_barrier();
+        // ---- prefetch: weights two steps ahead, patch slices of the next chunk -----------------------------------------
+        if (t < 7) issue_w((t + 2) % 3, t + 2, kc, cur.nblk, true);
+        else issue_w((t + 2) % 3, t + 2 - 9, kc_n, nxt.nblk, have_n);
+        if (NPB == 2) {
+#pragma unroll
+          for (int u = 0; u < SPT; ++u)
+            if (t * SPT + u < PJ) issue_slice(t * SPT + u, cbuf ^ 1, pn, kc_n, have_n);
+        }
+        compute_tap(t / 3, t % 3, t % 3, ab);
+      }
+      if (NPB == 1) {
+        raw_barrier();                            // every wave has issued the MFMAs of tap 8: the patch buffer is free
+#pragma unroll
+        for (int sl = 0; sl < PJ; ++sl) issue_slice(sl, 0, pn, kc_n, have_n);
+      }
+      boundary = last_kc;
+      if (last_kc) epilogue(cur);
+      cbuf ^= 1;
+    }
+    item += G;
+    if (item >= q.items) break;
+    if (nxt.nblk != cur.nblk) load_consts(nxt.nblk);
+    cur = nxt;
+  }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+static int lattice_enabled() {
+  static int v = -1;                              // UNETDC_LATTICE=0: round-1 kernels (A/B measurements)
+  if (v < 0) { const char* e = getenv("UNETDC_LATTICE"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v;
+}
+
+bool igemm_lattice_supported(const IgemmParams& p, int dtype) {
+  if (!lattice_enabled() || dtype != UNETDC_BF16) return false;
+  if (p.ntaps != 9 || p.stride != 1 || p.mode == MODE_SHUFFLE) return false;
+  if (p.Ho != p.Hi || p.Wo != p.Wi) return false;
+  const int d = p.offy[8];
+  if (d < 1 || p.offx[8] != d || p.offy[0] != -d || p.offx[0] != -d) return false;
+  if (p.Ho % d != 0 || p.Wo % d != 0) return false;
+  if ((p.Ho / d) % LTH != 0 || (p.Wo / d) % LTW != 0) return false;
+  if (p.Cin % 64 != 0 || p.Cout % 64 != 0) return false;
+  const long HoWo = (long)p.Ho * p.Wo;
+  if (p.M % HoWo != 0) return false;
+  const long xbytes = (p.M / HoWo) * p.Hi * p.Wi * p.ldx * 2L;
+  const long obytes = (long)p.M * p.ldo * 2, ybytes = p.mode == MODE_BNBWD ? (long)p.M * p.bn_ldy * 2 : 0;
+  const long wbytes = 9L * p.Cout * p.Cin * 2;
+  return xbytes < (1L << 31) && wbytes < (1L << 31) && obytes < (1L << 32) && ybytes < (1L << 32);
+}
+
+template <int WM, int WN, int MT, int NPB, int MODE>
+static int launch_lattice_cfg(IgemmParams& p, const LatticeParams& q, int wgs_per_cu, hipStream_t stream) {
+  constexpr int NW = WM * WN, BN = WN * 64;
+  constexpr int PJ = (LPI + NW - 1) / NW;
+  constexpr int LDS = NPB * PJ * NW * 1024 + 3 * BN * 128 + NW * 128 * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_lattice_kernel<WM, WN, MT, NPB, MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(igemm_lattice_kernel) failed: %s", hipGetErrorString(e));
+      return UNETDC_ELAUNCH;
+    }
+    attr_done = true;
+  }
+  // persistent grid: as many workgroups as fit the chip at once (256 CUs), never more than there are items
+  long grid = 256L * wgs_per_cu;
+  if (grid > q.items) grid = q.items;
+  hipLaunchKernelGGL((igemm_lattice_kernel<WM, WN, MT, NPB, MODE>), dim3((unsigned)grid), dim3(NW * 64), LDS, stream, p, q);
+  char nm[96];
+  snprintf(nm, sizeof(nm), "igemm_lattice_kernel<%d, %d, %d, %d, %d>", WM, WN, MT, NPB, MODE);
+  note_kernel(nm);
+  return check_launch("igemm_lattice_kernel");
+}
+
+template <int WM, int WN, int MT, int NPB>
+static int launch_lattice_mode(IgemmParams& p, const LatticeParams& q, int wgs, hipStream_t stream) {
+  switch (p.mode) {
+    case MODE_STATS: return launch_lattice_cfg<WM, WN, MT, NPB, MODE_STATS>(p, q, wgs, stream);
+    case MODE_AFFINE_RELU: return launch_lattice_cfg<WM, WN, MT, NPB, MODE_AFFINE_RELU>(p, q, wgs, stream);
+    case MODE_BNBWD: return launch_lattice_cfg<WM, WN, MT, NPB, MODE_BNBWD>(p, q, wgs, stream);
+    default: return launch_lattice_cfg<WM, WN, MT, NPB, MODE_STORE>(p, q, wgs, stream);
+  }
+}
+
+int launch_igemm_lattice(IgemmParams& p, hipStream_t stream) {
+  LatticeParams q{};
+  q.d = p.offy[8];
+  q.Hs = p.Ho / q.d;
+  q.Ws = p.Wo / q.d;
+  q.tiles_x = q.Ws / LTW;
+  q.tiles_y = q.Hs / LTH;
+  q.tiles_per_img = q.d * q.d * q.tiles_x * q.tiles_y;
+  q.nkc = p.Cin / 64;
+  const int nimg = (int)((long)p.M / ((long)p.Ho * p.Wo));
+  p.mblocks = nimg * q.tiles_per_img;             // = M / 256: one statistics row per tile
+  if (p.Cout % 128 == 0) {
+    q.nblocks = p.Cout / 128;
+    q.items = p.mblocks * q.nblocks;
+    p.nblocks = q.nblocks;
+    return launch_lattice_mode<4, 2, 4, 2>(p, q, 1, stream);
+  }
+  q.nblocks = p.Cout / 64;
+  q.items = p.mblocks * q.nblocks;
+  p.nblocks = q.nblocks;
+  return launch_lattice_mode<4, 1, 4, 1>(p, q, 2, stream);
+}
+
+}  // namespace unetdc

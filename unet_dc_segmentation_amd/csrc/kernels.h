@@ -30,6 +30,8 @@ struct IgemmParams {
 };
 int launch_igemm(IgemmParams& p, int dtype, hipStream_t stream);
 int igemm_mblocks(long M, int Cout);
+bool igemm_lattice_supported(const IgemmParams& p, int dtype);      // igemm_lattice.hip: persistent lattice-halo conv (bf16)
+int launch_igemm_lattice(IgemmParams& p, hipStream_t stream);
 bool igemm_dma16_supported(const IgemmParams& p, int dtype);
 int launch_igemm_dma16(IgemmParams& p, int cfg, hipStream_t stream);
 

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "kernels.h"
+#include "lds_dma.h"
 #include "wgrad_frag.h"
 
 namespace unetdc {
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_ring_kernel(const WgradFusedPara
   constexpr int NDY = PF + 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const xring = smem + NDY * DYB;
+  const unsigned lds_base = lds_addr_of(smem);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -245,8 +247,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_ring_kernel(const WgradFusedPara
     for (int q = 0; q < NQ; ++q) {
       const int gi = wave + 4 * q;
       if (gi >= DYI && gi < GI) {
-        const unsigned v = (yok && colb[q] != FOOB) ? rowbase + colb[q] : FOOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, LDS_PTR(xring + slot * XB + (gi - DYI) * 1024), 16, v, 0, 0, 0);
+        const unsigned v = (yok && colb[q] != FOOB) ? colb[q] : FOOB;
+        lds_dma16(xr, lds_base + NDY * DYB + slot * XB + (gi - DYI) * 1024, v, rowbase);
       }
     }
   };
@@ -255,8 +257,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_ring_kernel(const WgradFusedPara
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int gi = wave + 4 * q;
-      if (gi < DYI)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(dyr, LDS_PTR(smem + slot * DYB + gi * 1024), 16, rowbase + colb[q], 0, 0, 0);
+      if (gi < DYI) lds_dma16(dyr, lds_base + slot * DYB + gi * 1024, colb[q], rowbase);
     }
   };
 
@@ -286,7 +287,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_ring_kernel(const WgradFusedPara
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __syncthreads();
+    // Raw barrier behind the counted wait (lds_dma.h: with the builtin DMA + __syncthreads() of round 1 the binary
+    // drained the VM counter twice per step -- `vmcnt(4|5) ; vmcnt(0) ; s_barrier` here and another compiler-inserted
+    // `vmcnt(0)` in front of the first fragment read -- so the group issued for step s+2 never stayed in flight).
+    raw_barrier();
     if (s + PF < nsteps) {
       issue_dy(gslot_dy, ybeg + s + PF);
       issue_x(gslot_x, ybeg + s + PF + d);
