@@ -333,7 +333,8 @@ def main():
     ap.add_argument("--arch", default="unetdc", choices=["unetdc", "unet"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
-    ap.add_argument("--adam", choices=["fused", "foreach"], default="fused", help="torch.optim.Adam implementation")
+    ap.add_argument("--adam", choices=["hip", "fused", "foreach"], default="hip",
+                    help="hip = this repo's one-kernel Adam + weight re-pack (default); fused / foreach = torch.optim.Adam")
     ap.add_argument("--per-layer", action="store_true", help="print a per-call timing table to stderr (diagnostic)")
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
                     help="train = the headline metric (default); infer = forward-only eval (BASELINE configs[1])")
@@ -364,9 +365,13 @@ def main():
     model = Net(in_channels=args.in_channels, out_channels=1).to(dev).train()
     model.set_compute_dtype(args.dtype)
     wrapper = dpmod.DataParallel(model) if world > 1 else None
-    # train_DC_focal.py:224 (Adam, lr 1e-3).  fused=True is PyTorch's single multi-tensor kernel for the same update
-    # (the default foreach implementation spends 0.5 ms per step in eight elementwise passes over 31 M parameters)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=(args.adam == "fused"))
+    # train_DC_focal.py:224 (Adam, lr 1e-3): the same update rule in ONE HIP kernel that also rewrites the packed weight
+    # images (unet_dc_segmentation_amd/optim.py); --adam fused / foreach select torch.optim.Adam for comparison
+    if args.adam == "hip":
+        from unet_dc_segmentation_amd.optim import FusedAdam
+        opt = FusedAdam(model, lr=1e-3)
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=(args.adam == "fused"))
     x, t = synthetic_batch(1000 + rank, args.batch, args.size, args.size, args.in_channels)
     x, t = x.to(dev), t.to(dev)
 
@@ -460,7 +465,7 @@ def main():
                                    (f"eval forward + 0.3 threshold, {args.arch} bs={args.batch}/GPU "
                                     f"{args.size}x{args.size}x{args.in_channels} (BASELINE configs[1])"),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "timed_region": "zero_grad, model(x), focal_dice_loss, backward, all-reduce, Adam step, weight re-pack"
+                       "timed_region": "zero_grad, model(x), focal_dice_loss, backward, all-reduce, Adam step (" + args.adam + "), weight re-pack"
                                        if args.mode == "train" else "model(x) under no_grad + threshold, input resident in HBM"},
             "roofline": roofline,
             "hbm_leg": hbm,

@@ -69,6 +69,27 @@ typedef struct unetdc_pack_desc {
 } unetdc_pack_desc;
 int unetdc_pack_many(const unetdc_pack_desc* table_dev, int n, int64_t total_tiles, int dtype, unetdc_stream_t s);
 
+/* ---- optimizer step ---------------------------------------------------------------------------
+ * Replaces `optimizer.step()` of torch.optim.Adam (/root/reference/train_DC_focal.py:224,255; train.py:125) AND the
+ * re-pack above, in one launch: for every parameter   g <- grad_scale * g;   m <- m + (1-beta1)(g - m);
+ * v <- beta2 v + (1-beta2) g g;   p <- p - lr/(1-beta1^step) * m / (sqrt(v)/sqrt(1-beta2^step) + eps)
+ * (torch's _fused_adam_ formulation; no weight decay / amsgrad, which the reference does not use), and the packed
+ * images of the conv / convT weights are rewritten from the NEW p.
+ * `table_dev`: DEVICE array of n descriptors sorted by `begin` (first workgroup of the tensor); a packed tensor takes
+ * (a/32)*(b/32) workgroups, a plain one ceil(numel/4096); `total_blocks` = the grand total.  The gradient of tensor i is
+ * flat_grad[g_off .. g_off + numel): the flat fp32 buffer the backward kernels write (parameters() order).
+ * wf / wd may be NULL for a packed-kind tensor (then only p, m, v are updated).  `step` counts from 1. */
+typedef struct unetdc_adam_desc {
+  float* p; float* m; float* v;   /* fp32 master parameter, exp_avg, exp_avg_sq (same layout as p) */
+  void* wf; void* wd;             /* packed images in `dtype`, or NULL */
+  int64_t g_off, begin, numel;
+  int32_t a, b;                   /* kind 0: (cout, cin); kind 1: (cin, cout); kind 2: unused */
+  int32_t kind;                   /* 0 conv3x3 (packed), 1 convT2x2 (packed), 2 plain */
+  int32_t pad;
+} unetdc_adam_desc;
+int unetdc_adam_step(const unetdc_adam_desc* table_dev, int n, int64_t total_blocks, const float* flat_grad, double lr,
+                     double beta1, double beta2, double eps, int64_t step, double grad_scale, int dtype, unetdc_stream_t s);
+
 /* ---- dilated 3x3 convolution, padding = dilation: nn.Conv2d at models/model_2.py:41-44,48-51 ---
  * y = conv(x) + bias                                  (scale == NULL; training: raw pre-BN output)
  * y = relu(conv(x)*scale + shift)                     (scale != NULL; eval: BN folded, bias inside shift)

@@ -205,3 +205,26 @@ def test_bench_roofline_bookkeeping():
     assert bench.hbm_bytes("unetdc_bn_relu_apply", apply_args, 2) == 8 * 512 * 512 * 64 * 2 * 2.25
     h1, h2 = bench.kernel_source_hash(), bench.kernel_source_hash()
     assert h1 == h2 and len(h1) == 16
+
+
+def test_fused_adam_cpu_formulas_match_torch():
+    """On CPU tensors FusedAdam runs the per-tensor formulas in PyTorch (the reference's own path on a host without a
+    GPU): same numbers as torch.optim.Adam, same state_dict layout."""
+    from models.model_2 import UNetDC
+    from unet_dc_segmentation_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    a, b = UNetDC(1, 1), UNetDC(1, 1)
+    b.load_state_dict(a.state_dict())
+    oa, ob = FusedAdam(a, lr=1e-2), torch.optim.Adam(b.parameters(), lr=1e-2)
+    g = torch.Generator().manual_seed(1)
+    for _ in range(3):
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            pa.grad = torch.randn(pa.shape, generator=g)
+            pb.grad = pa.grad.clone()
+        oa.step()
+        ob.step()
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-6, atol=1e-8)
+    sda, sdb = oa.state_dict(), ob.state_dict()
+    assert sda["state"].keys() == sdb["state"].keys() and set(sda["state"][0]) == set(sdb["state"][0])
+    assert torch.allclose(sda["state"][0]["exp_avg"], sdb["state"][0]["exp_avg"], rtol=1e-6, atol=1e-10)

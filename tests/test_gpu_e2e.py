@@ -471,3 +471,48 @@ def test_quantify_cli_on_gpu_512(tmp_path):
         mine = drops[drops["filename"] == f"im{i}.png"]
         assert len(mine) == len(d) and abs(mine["area"].sum() - d["area"].sum()) < 1e-9
         assert int(summary[summary["filename"] == f"im{i}.png"]["droplet_count"].iloc[0]) == len(d)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_fused_adam_matches_torch_adam_and_refreshes_packed_weights(dtype):
+    """unet_dc_segmentation_amd.optim.FusedAdam (csrc/optim.hip: Adam + weight re-pack in one kernel) against
+    torch.optim.Adam over 3 steps on identical gradients: parameters and both moments equal to a few ulps (same update
+    rule, one fma of difference), then an eval forward must use the UPDATED weights although no pack launch ran
+    (the optimizer wrote the packed images itself)."""
+    from unet_dc_segmentation_amd.optim import FusedAdam
+    from utils.metrics_DC import focal_dice_loss
+    model_a, g = build_model("dc_c1", "train")
+    model_b, _ = build_model("dc_c1", "train")
+    model_a, model_b = model_a.cuda().train(), model_b.cuda().train()
+    model_a.set_compute_dtype(dtype)
+    model_b.set_compute_dtype(dtype)
+    x, t = torch.from_numpy(g["train_x"]).cuda(), torch.from_numpy(g["train_t"]).cuda()
+    opt_a = FusedAdam(model_a, lr=1e-2)
+    opt_b = torch.optim.Adam(model_b.parameters(), lr=1e-2)
+    for k in range(3):
+        for m, o in ((model_a, opt_a), (model_b, opt_b)):
+            o.zero_grad(set_to_none=True)
+            focal_dice_loss(m(x * (1 - 0.1 * k)), t, alpha=1.0, gamma=2.0, ratio=0.3).backward()
+        with torch.no_grad():                                # feed B's optimizer the same gradients: isolates the update rule
+            for pa, pb in zip(model_a.parameters(), model_b.parameters()):
+                pb.grad.copy_(pa.grad)
+        opt_a.step()
+        opt_b.step()
+        for (k_, pa), pb in zip(model_a.named_parameters(), model_b.parameters()):
+            scale = float(pb.detach().abs().max())
+            assert float((pa - pb).abs().max()) <= 4e-6 * scale + 1e-9, (k, k_)
+            sa, sb = opt_a.state[pa], opt_b.state[pb]
+            assert float((sa["exp_avg"] - sb["exp_avg"]).abs().max()) <= 2e-6 * float(sb["exp_avg"].abs().max()) + 1e-12
+            assert float((sa["exp_avg_sq"] - sb["exp_avg_sq"]).abs().max()) <= 2e-6 * float(sb["exp_avg_sq"].abs().max()) + 1e-20
+    assert int(float(opt_a.state[next(model_a.parameters())]["step"])) == 3
+    # the packed images follow without a re-pack launch
+    model_a.eval()
+    with torch.no_grad():
+        p_after = model_a(x).cpu()
+    sd = {k: v.detach().cpu().clone() for k, v in model_a.state_dict().items()}
+    p_ref = otc.unet_forward(x.cpu(), sd, dict(model_a.DILATIONS), train=False, emulate_bf16=(dtype == "bf16"))
+    assert float((p_after - p_ref).abs().max()) < (1e-4 if dtype == "f32" else 3e-2)
+    # state_dict round trip into torch.optim.Adam
+    opt_c = torch.optim.Adam(model_a.parameters(), lr=1e-2)
+    opt_c.load_state_dict(opt_a.state_dict())
+    assert torch.equal(opt_c.state[next(model_a.parameters())]["exp_avg"], opt_a.state[next(model_a.parameters())]["exp_avg"])

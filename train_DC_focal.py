@@ -39,6 +39,8 @@ def build_parser(arch="unetdc", epochs=15, ckpt="best_UNetDC_focal_model.pth", l
     p.add_argument("--loss", default=loss, choices=["focal_dice", "bce_dice"])
     p.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     p.add_argument("--steps", type=int, default=0, help="max training steps per epoch (0 = all)")
+    p.add_argument("--optimizer", default="hip", choices=["hip", "torch"],
+                   help="Adam implementation on a GPU: hip = fused step + weight re-pack kernel, torch = torch.optim.Adam")
     p.add_argument("--workers", type=int, default=4)
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--ckpt_path", default=ckpt)
@@ -88,8 +90,13 @@ def main(argv=None, parser=None):
         criterion = lambda pred, tgt: focal_dice_loss(pred, tgt, alpha=1.0, gamma=2.0, ratio=0.3)  # noqa: E731
     else:
         criterion = combined_loss
-    # same update as the reference's torch.optim.Adam(lr) (train_DC_focal.py:224); fused = one multi-tensor kernel on the GPU
-    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, fused=next(model.parameters()).is_cuda)
+    # same update as the reference's torch.optim.Adam(lr) (train_DC_focal.py:224).  On the HIP path: one kernel that also
+    # rewrites the packed weight images (unet_dc_segmentation_amd/optim.py); --optimizer torch keeps torch.optim.Adam
+    if device.type == "cuda" and args.optimizer == "hip":
+        from unet_dc_segmentation_amd.optim import FusedAdam
+        optimizer = FusedAdam(model, lr=args.lr)
+    else:
+        optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, fused=next(model.parameters()).is_cuda)
 
     train_ds, val_ds, _ = make_datasets(args)
     if world > 1:

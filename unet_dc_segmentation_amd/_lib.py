@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 
 import torch  # noqa: F401  (must be imported before the CDLL below -- see module docstring)
 
@@ -17,7 +17,7 @@ F32, BF16 = 0, 1
 LIB_NAME = "libunetdc_hip.so"
 LIB_PATH = os.environ.get("UNETDC_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
-P, I, L, F = c_void_p, c_int, c_int64, c_float
+P, I, L, F, D = c_void_p, c_int, c_int64, c_float, c_double
 
 # name -> (restype, argtypes); mirrors include/unetdc_hip.h one to one
 SIGNATURES = {
@@ -27,6 +27,7 @@ SIGNATURES = {
     "unetdc_pack_conv3x3": (I, [P, P, P, I, I, I, P]),
     "unetdc_pack_convT2x2": (I, [P, P, P, I, I, I, P]),
     "unetdc_pack_many": (I, [P, I, L, I, P]),
+    "unetdc_adam_step": (I, [P, I, L, P, D, D, D, D, L, D, I, P]),
     "unetdc_conv3x3_stats_rows": (I, [L, I]),
     "unetdc_conv3x3_fwd": (I, [P, I, P, P, P, P, P, I, P, I, I, I, I, I, I, I, P]),
     "unetdc_conv3x3_dgrad": (I, [P, I, P, P, I, I, I, I, I, I, I, I, P]),

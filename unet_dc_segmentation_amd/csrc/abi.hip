@@ -61,6 +61,13 @@ int unetdc_pack_many(const unetdc_pack_desc* table_dev, int n, int64_t total_til
   return launch_pack_many(table_dev, n, (long)total_tiles, dtype, (hipStream_t)s);
 }
 
+int unetdc_adam_step(const unetdc_adam_desc* table_dev, int n, int64_t total_blocks, const float* flat_grad, double lr,
+                     double beta1, double beta2, double eps, int64_t step, double grad_scale, int dtype, unetdc_stream_t s) {
+  static_assert(sizeof(unetdc_adam_desc) == 80, "unetdc_adam_desc layout");
+  return launch_adam_step(table_dev, n, (long)total_blocks, flat_grad, lr, beta1, beta2, eps, (long)step, grad_scale, dtype,
+                          (hipStream_t)s);
+}
+
 int unetdc_conv3x3_stats_rows(int64_t npixels, int cout) { return igemm_mblocks((long)npixels, cout); }
 
 int unetdc_conv3x3_fwd(const void* x, int ldx, const void* w_fwd, const float* bias, const float* scale,

@@ -52,6 +52,8 @@ struct LatticeParams {
   int nblocks;                // Cout / BN
   int items;                  // N * tiles_per_img * nblocks
   int nkc;                    // Cin / 64
+  unsigned mg_nblocks, mg_tpi, mg_tpp, mg_d, mg_tx;   // ceil(2^32 / divisor) for the item decode (exact for n * divisor < 2^32)
+  int dbg;                    // UNETDC_LAT_DBG (timing experiments only, results invalid): 1 no tap barriers, 2 no DMA waits, 8 no DMA
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -83,22 +85,34 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
   const int G = gridDim.x;
   const int d = q.d;
 
-  const unsigned xbytes = (unsigned)((long)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.ldx * 2);
+  // The patch origin (-1, -1) of a border tile lies in front of the tensor; the scalar part of a DMA address (soffset)
+  // cannot be negative, so the descriptor starts SH bytes early (those bytes are never touched: halo lanes outside the
+  // image carry an out-of-range voffset and read zeros).
+  const unsigned SH = (unsigned)((d * p.Wi + d) * p.ldx * 2);
+  const unsigned xbytes = (unsigned)((long)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.ldx * 2) + SH;
   const unsigned wbytes = (unsigned)((long)9 * p.Cout * p.Cin * 2);
-  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.x)) - SH, 0, xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, wbytes, 0x00020000);
 
   // ---- per-lane constants --------------------------------------------------------------------------------------
   const int sub = lane >> 3, pc = lane & 7;
   // patch slice sl of this wave = DMA instruction wave + NW*sl = patch pixels 8*instr .. 8*instr+7 (row-major in the
   // 10 x 34 patch); this lane feeds pixel pr, physical chunk pc <- logical chunk pc ^ key(column)
-  unsigned prc[PJ];                               // ppy | ppx << 8 | chunk byte offset << 16 | invalid << 31
+  unsigned prel[PJ];                              // byte offset of the lane's 16-byte piece relative to the patch origin
+  unsigned pflg[(PJ + 3) / 4];                    // 8 flag bits per slice: 1 top halo row, 2 bottom, 4 left halo column, 8 right,
+                                                  //                       16 padding row of the buffer, 32 always
+#pragma unroll
+  for (int w4 = 0; w4 < (PJ + 3) / 4; ++w4) pflg[w4] = 0;
 #pragma unroll
   for (int sl = 0; sl < PJ; ++sl) {
     const int pr = (wave + NW * sl) * 8 + sub;
     const int ppy = (pr * 1928) >> 16, ppx = pr - ppy * LPW;       // pr / 34 for pr < 1024
     const int ch = pc ^ ((ppx >> 1) & 7);
-    prc[sl] = (unsigned)ppy | ((unsigned)ppx << 8) | ((unsigned)(ch * 16) << 16) | (pr < LPP ? 0u : 0x80000000u);
+    prel[sl] = (unsigned)(((ppy * d) * p.Wi + ppx * d) * p.ldx * 2 + ch * 16);
+    const unsigned f = (ppy == 0 ? 1u : 0u) | (ppy == LPH - 1 ? 2u : 0u) | (ppx == 0 ? 4u : 0u) | (ppx == LPW - 1 ? 8u : 0u) |
+                       (pr >= LPP ? 16u : 0u) | 32u;
+    pflg[sl >> 2] |= f << (8 * (sl & 3));
   }
   // weight rows: LDS row lrow of the stage = N tile (q >> 4) of its 64-channel group, column q & 15
   //   <-> output channel 4*(q & 15) + (q >> 4): the four N tiles of a lane hold four consecutive channels
@@ -128,18 +142,23 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
 
   // ---- work items ---------------------------------------------------------------------------------------------------
   struct Item { int img, phy, phx, ly0, lx0, nblk, mtile; };
+  // v_mul_hi_u32 is a VALU instruction: readfirstlane brings the (wave-uniform) quotient back to an SGPR, which is what
+  // the scalar operands of the DMA statements need
+  auto udiv = [](unsigned n, unsigned magic, unsigned dv) {
+    return dv == 1 ? n : (unsigned)__builtin_amdgcn_readfirstlane((int)__umulhi(n, magic));
+  };
   auto decode = [&](int item) {
     Item it;
-    it.nblk = item % q.nblocks;
-    it.mtile = item / q.nblocks;
-    it.img = it.mtile / q.tiles_per_img;
+    it.mtile = (int)udiv((unsigned)item, q.mg_nblocks, (unsigned)q.nblocks);
+    it.nblk = item - it.mtile * q.nblocks;
+    it.img = (int)udiv((unsigned)it.mtile, q.mg_tpi, (unsigned)q.tiles_per_img);
     int r = it.mtile - it.img * q.tiles_per_img;
     const int tpp = q.tiles_x * q.tiles_y;        // tiles per phase
-    const int ph = r / tpp;
+    const int ph = (int)udiv((unsigned)r, q.mg_tpp, (unsigned)tpp);
     r -= ph * tpp;
-    it.phy = ph / d;
+    it.phy = (int)udiv((unsigned)ph, q.mg_d, (unsigned)d);
     it.phx = ph - it.phy * d;
-    const int ty = r / q.tiles_x;
+    const int ty = (int)udiv((unsigned)r, q.mg_tx, (unsigned)q.tiles_x);
     it.ly0 = ty * LTH;
     it.lx0 = (r - ty * q.tiles_x) * LTW;
     return it;
@@ -148,14 +167,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
   if (first >= q.items) return;                   // (grid <= items: never taken)
 
   // ---- DMA issue -----------------------------------------------------------------------------------------------------
-  auto issue_slice = [&](int sl, int buf, const Item& it, int kc, bool valid) {
-    const unsigned pk = prc[sl];
-    const int ly = it.ly0 - 1 + (int)(pk & 0xffu), lx = it.lx0 - 1 + (int)((pk >> 8) & 0xffu);
-    const bool ok = valid && (int)pk >= 0 && (unsigned)ly < (unsigned)q.Hs && (unsigned)lx < (unsigned)q.Ws;
-    const int Y = ly * d + it.phy, X = lx * d + it.phx;
-    const unsigned voff = ok ? (unsigned)((Y * p.Wi + X) * p.ldx * 2) + ((pk >> 16) & 0xffu) : LOOB;
-    const unsigned soff = (unsigned)(it.img * p.Hi * p.Wi * p.ldx * 2 + kc * 128);
-    lds_dma16(xr, lds_base + buf * PBUF + (wave + NW * sl) * 1024, voff, soff);
+  // scalar description of the patch of (item, K chunk): byte offset of its origin (+SH) and which borders it touches
+  auto patch_base = [&](const Item& it, int kc) {
+    return (unsigned)((((it.img * p.Hi + (it.ly0 - 1) * d + it.phy) * p.Wi + (it.lx0 - 1) * d + it.phx) * p.ldx) * 2 + kc * 128) + SH;
+  };
+  auto patch_edges = [&](const Item& it, bool valid) {
+    return valid ? ((it.ly0 == 0 ? 1u : 0u) | (it.ly0 + LTH == q.Hs ? 2u : 0u) | (it.lx0 == 0 ? 4u : 0u) |
+                    (it.lx0 + LTW == q.Ws ? 8u : 0u) | 16u)
+                 : 32u;
+  };
+  auto issue_slice = [&](int sl, int buf, unsigned pbase, unsigned edges) {
+    const unsigned f = (pflg[sl >> 2] >> (8 * (sl & 3))) & edges;
+    lds_dma16(xr, lds_base + buf * PBUF + (wave + NW * sl) * 1024, f ? LOOB : prel[sl], pbase);
   };
   auto issue_w = [&](int stage, int tap, int kc, int nblk, bool valid) {
     const unsigned soff = (unsigned)(((tap * p.Cout + nblk * BN) * p.Cin + kc * 64) * 2);
@@ -165,15 +188,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
   };
 
   f32x4 acc[MT][4];
+  float binit[4] = {0.f, 0.f, 0.f, 0.f};          // conv bias of this lane's four channels: the accumulators START from it
   auto zero_acc = [&]() {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = binit[j];
   };
-  zero_acc();
 
   // one tap: fragments of both 32-channel halves, MT*4*2 MFMAs
   auto compute_tap = [&](int ky, int kx, int stage, const int (&ab)[3][2]) {
@@ -200,7 +223,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
   const unsigned ldob = (unsigned)(p.ldo * 2), ldyb = (unsigned)(p.bn_ldy * 2);
   const int xb = (rb == 0) ? 0 : (rb == 1 ? 1 : (rb == 2 ? 9 : 8));          // pixel of accumulator row 4*rb + v = xb + 2v
   Epi16Consts ec;
-  auto load_consts = [&](int nblk) { ec = epi16_consts<MODE>(p, nblk * BN + wn * 64 + 4 * c16); };
+  auto load_consts = [&](int nblk) {
+    ec = epi16_consts<MODE>(p, nblk * BN + wn * 64 + 4 * c16);
+    if (MODE == MODE_STORE || MODE == MODE_STATS) {        // "+ bias" modes: fold it into the accumulator init
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { binit[k] = ec.k1[k]; ec.k1[k] = 0.f; }
+    }
+  };
   auto epilogue = [&](const Item& it) {
     bool tile_ok[MT];
     unsigned voff[MT], yoff[MT];
@@ -259,10 +288,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
   Item cur = decode(first), nxt = cur;
   int item = first;
   load_consts(cur.nblk);
+  zero_acc();
   {
     if (NPB == 1) { issue_w(0, 0, 0, cur.nblk, true); issue_w(1, 1, 0, cur.nblk, true); }
 #pragma unroll
-    for (int sl = 0; sl < PJ; ++sl) issue_slice(sl, 0, cur, 0, true);
+    for (int sl = 0; sl < PJ; ++sl) issue_slice(sl, 0, patch_base(cur, 0), patch_edges(cur, true));
     if (NPB == 2) { issue_w(0, 0, 0, cur.nblk, true); issue_w(1, 1, 0, cur.nblk, true); }
   }
   int cbuf = 0;
@@ -273,13 +303,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
       const int item_n = last_kc ? item + G : item, kc_n = last_kc ? 0 : kc + 1;
       const bool have_n = item_n < q.items;
       if (last_kc) nxt = have_n ? decode(item_n) : cur;
-      Item pn;                                      // whose patch the next chunk needs (wave-uniform selects, no references:
-      pn.img = last_kc ? nxt.img : cur.img;         //  a reference to one of two structs sends both to scratch memory)
-      pn.phy = last_kc ? nxt.phy : cur.phy;
-      pn.phx = last_kc ? nxt.phx : cur.phx;
-      pn.ly0 = last_kc ? nxt.ly0 : cur.ly0;
-      pn.lx0 = last_kc ? nxt.lx0 : cur.lx0;
-      pn.nblk = 0; pn.mtile = 0;
+      // the patch the next chunk needs: same item, next 64 channels -- or the next item's first chunk
+      // (readfirstlane: a select between two uniform values can come out of the compiler as a VGPR phi, which the
+      //  scalar operand of a DMA statement cannot take; the DMAs that read it are a barrier and a wait further down)
+      const unsigned pb_n = (unsigned)__builtin_amdgcn_readfirstlane((int)(last_kc ? patch_base(nxt, 0) : patch_base(cur, kc_n)));
+      const unsigned pe_n = (unsigned)__builtin_amdgcn_readfirstlane((int)(last_kc ? patch_edges(nxt, have_n) : patch_edges(cur, true)));
+      const int nblk_n = __builtin_amdgcn_readfirstlane(nxt.nblk);
       int ab[3][2];
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx)
@@ -288,7 +317,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         // ---- wait for the weights of this step (and, at t = 0, the patch of this chunk) -------------------------------
-        if (NPB == 2) {
+        if (q.dbg & 2) {
+        } else if (NPB == 2) {
           constexpr int nA = lat_nsl<PJ, SPT>(0);
           if (t == 0) { if (boundary) wait_vmcnt<BI + NST>(); else wait_vmcnt<BI>(); }
           else if (t == 1) { if (boundary) wait_vmcnt<BI + nA + NST>(); else wait_vmcnt<BI + nA>(); }
@@ -305,21 +335,23 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
           if (t == 0) { if (boundary) wait_vmcnt<NST>(); else wait_vmcnt<0>(); }
           else wait_vmcnt<BI>();
         }
-        raw_barrier();
+        if (!(q.dbg & 1)) raw_barrier();
         // ---- prefetch: weights two steps ahead, patch slices of the next chunk -----------------------------------------
-        if (t < 7) issue_w((t + 2) % 3, t + 2, kc, cur.nblk, true);
-        else issue_w((t + 2) % 3, t + 2 - 9, kc_n, nxt.nblk, have_n);
-        if (NPB == 2) {
+        if (q.dbg & 8) {
+        } else if (t < 7) issue_w((t + 2) % 3, t + 2, kc, cur.nblk, true);
+        else issue_w((t + 2) % 3, t + 2 - 9, kc_n, nblk_n, have_n);
+        if (NPB == 2 && !(q.dbg & 8)) {
 #pragma unroll
           for (int u = 0; u < SPT; ++u)
-            if (t * SPT + u < PJ) issue_slice(t * SPT + u, cbuf ^ 1, pn, kc_n, have_n);
+            if (t * SPT + u < PJ) issue_slice(t * SPT + u, cbuf ^ 1, pb_n, pe_n);
         }
         compute_tap(t / 3, t % 3, t % 3, ab);
       }
       if (NPB == 1) {
         raw_barrier();                            // every wave has issued the MFMAs of tap 8: the patch buffer is free
 #pragma unroll
-        for (int sl = 0; sl < PJ; ++sl) issue_slice(sl, 0, pn, kc_n, have_n);
+        for (int sl = 0; sl < PJ; ++sl)
+          if (!(q.dbg & 8)) issue_slice(sl, 0, pb_n, pe_n);
       }
       boundary = last_kc;
       if (last_kc) epilogue(cur);
@@ -327,7 +359,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
     }
     item += G;
     if (item >= q.items) break;
-    if (nxt.nblk != cur.nblk) load_consts(nxt.nblk);
+    if (nxt.nblk != cur.nblk) { load_consts(nxt.nblk); zero_acc(); }
     cur = nxt;
   }
 #endif
@@ -401,16 +433,26 @@ int launch_igemm_lattice(IgemmParams& p, hipStream_t stream) {
   q.tiles_y = q.Hs / LTH;
   q.tiles_per_img = q.d * q.d * q.tiles_x * q.tiles_y;
   q.nkc = p.Cin / 64;
+  auto magic = [](unsigned dv) { return dv <= 1 ? 0u : (unsigned)(((1ull << 32) + dv - 1) / dv); };
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("UNETDC_LAT_DBG"); dbg = e ? atoi(e) : 0; }
+    q.dbg = dbg;
+  }
   const int nimg = (int)((long)p.M / ((long)p.Ho * p.Wo));
   p.mblocks = nimg * q.tiles_per_img;             // = M / 256: one statistics row per tile
   if (p.Cout % 128 == 0) {
     q.nblocks = p.Cout / 128;
     q.items = p.mblocks * q.nblocks;
+    q.mg_nblocks = magic(q.nblocks); q.mg_tpi = magic(q.tiles_per_img); q.mg_tpp = magic(q.tiles_x * q.tiles_y);
+    q.mg_d = magic(q.d); q.mg_tx = magic(q.tiles_x);
     p.nblocks = q.nblocks;
     return launch_lattice_mode<4, 2, 4, 2>(p, q, 1, stream);
   }
   q.nblocks = p.Cout / 64;
   q.items = p.mblocks * q.nblocks;
+  q.mg_nblocks = magic(q.nblocks); q.mg_tpi = magic(q.tiles_per_img); q.mg_tpp = magic(q.tiles_x * q.tiles_y);
+  q.mg_d = magic(q.d); q.mg_tx = magic(q.tiles_x);
   p.nblocks = q.nblocks;
   return launch_lattice_mode<4, 1, 4, 1>(p, q, 2, stream);
 }

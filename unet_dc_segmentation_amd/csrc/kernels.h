@@ -113,6 +113,8 @@ int launch_head_bwd(HeadParams& p, float* dw, float* db, void* workspace, long w
 int launch_pack_conv3x3(const float* w, void* wf, void* wd, int Co, int Ci, int dtype, hipStream_t stream);
 int launch_pack_convT2x2(const float* w, void* wf, void* wd, int Ci, int Co, int dtype, hipStream_t stream);
 int launch_pack_many(const void* table_dev, int n, long total, int dtype, hipStream_t stream);
+int launch_adam_step(const void* table_dev, int n, long total_blocks, const float* flat_grad, double lr, double beta1,
+                     double beta2, double eps, long step, double grad_scale, int dtype, hipStream_t stream);   // optim.hip
 int launch_stats_colsum(const float* parts, int nparts, int ctotal, int c0, int c, float* out, hipStream_t stream);
 long channel_sum_workspace_bytes(long P, int C);
 int launch_channel_sum(const void* x, int ldx, float* out, void* workspace, long workspace_bytes, long P, int C,

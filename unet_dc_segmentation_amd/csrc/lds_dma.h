@@ -29,14 +29,17 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
 
 // One wave-instruction: 64 lanes x 16 bytes, lane l lands at lds_dst + 16*l; lane source = base + voff + soff.
 // voff beyond the descriptor's range (e.g. 0x80000000) -> the hardware writes zeros (soff is not range-checked).
-// lds_dst and soff must be wave-uniform (SGPRs produced by SALU code); M0 is saved and restored inside the statement
-// (the compiler treats M0 as its own); s_nop 0 = the SALU-writes-M0 -> LDS-DMA wait state.
+// lds_dst and soff must be wave-uniform; M0 is saved and restored inside the statement (the compiler treats M0 as its
+// own).  s_nop 2: with the two s_mov in front of it the DMA issues >= 5 wait states after the statement starts, which
+// covers both "SALU writes M0 -> LDS-DMA" and "v_readfirstlane writes an SGPR -> VMEM reads it as soffset" (hipcc pads
+// no hazard whose consumer sits inside an asm string).  "vcc" is clobbered only to keep the register allocator from
+// handing vcc_lo to an "s" operand: MUBUF does not accept it as soffset.
 __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned lds_dst, unsigned voff, unsigned soff) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 2\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
                : "v"(voff), "s"(lds_dst), "s"(rsrc), "s"(soff)
-               : "memory");
+               : "memory", "vcc");
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
