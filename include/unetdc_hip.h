@@ -212,6 +212,22 @@ int64_t unetdc_channel_sum_workspace(int64_t npixels, int c);
 int unetdc_channel_sum(const void* x, int ldx, float* out, void* workspace, int64_t workspace_bytes,
                        int64_t npixels, int c, int dtype, unetdc_stream_t s);
 
+/* ---- droplet quantification: /root/reference/quantify_droplets_batch.py:56-57,81-95 ----------
+ * unetdc_mask_from_probs: mask[y][x] = probs[sy][sx] > thresh (strict, fp32) with the nearest-neighbour index rule of
+ *   cv2.resize(..., INTER_NEAREST): s = min(floor(d * src/dst), src-1); probs [ph][pw] fp32 (one image, one channel),
+ *   mask [oh][ow] uint8 {0,1}.
+ * unetdc_ccl_stats: 4-connected components of a {0,1} mask, objects smaller than min_area dropped, the rest numbered in
+ *   raster order of their first pixel (= skimage.measure.label twice + regionprops order).  Outputs, per kept object in
+ *   that order: out_area (pixels), out_sumy / out_sumx (sums of row / column indices: centroid = sum / area),
+ *   out_root (linear index of the first pixel; may be NULL); *out_count = number of kept objects (may exceed max_out:
+ *   only the first max_out are written).  All outputs are DEVICE pointers.  Exact integer arithmetic, order-independent. */
+int unetdc_mask_from_probs(const float* probs, int ph, int pw, float thresh, uint8_t* mask, int oh, int ow,
+                           unetdc_stream_t s);
+int64_t unetdc_ccl_workspace(int h, int w);
+int unetdc_ccl_stats(const uint8_t* mask, int h, int w, int min_area, void* workspace, int64_t workspace_bytes,
+                     int32_t* out_count, int32_t* out_area, int64_t* out_sumy, int64_t* out_sumx, int32_t* out_root,
+                     int max_out, unetdc_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

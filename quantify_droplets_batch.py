@@ -8,8 +8,12 @@ Flow (reference lines): load_model :34-37 -> preprocess :40-46 (RGB, rolling bal
 to the original size, mask PNG, per-image CSV) -> quantify :81-95 (4-connected components, area
 filter, area / equivalent diameter / centroid) -> summary CSV / XLSX / histogram :163-199.
 The network runs on the HIP kernels when a GPU is present (``DEVICE = "cuda"``), otherwise on
-PyTorch-CPU exactly like the reference.  cv2 / scikit-image are optional: SciPy's ``ndimage.label``
-with its default cross-shaped structure is skimage's ``label(connectivity=1)``.
+PyTorch-CPU exactly like the reference.  On the GPU the threshold, the nearest-neighbour resize to the original
+size, the connected-component labelling and the per-droplet sums run on the device as well
+(unet_dc_segmentation_amd/droplets.py, csrc/ccl.hip): only the uint8 mask and three integers per droplet are
+copied back.  cv2 / scikit-image are optional on the CPU path: SciPy's ``ndimage.label`` with its default
+cross-shaped structure is skimage's ``label(connectivity=1)``, and the nearest-neighbour resize restates cv2's
+index rule (PIL's NEAREST samples pixel centres and picks different source pixels).
 """
 import argparse
 from pathlib import Path
@@ -20,6 +24,7 @@ import torch
 from PIL import Image
 
 from models.model_2 import UNetDC
+from unet_dc_segmentation_amd.droplets import resize_nearest_cv2
 from utils.data_loader import resize_image, rolling_ball_correction_rgb
 
 DEVICE = "cuda" if torch.cuda.is_available() else "cpu"
@@ -41,10 +46,25 @@ def preprocess(path, background_radius):
     return torch.from_numpy(im).permute(2, 0, 1), (oh, ow)
 
 
+def _droplet_table(area, cen_row, cen_col, px_per_um):
+    """DataFrame with the reference's columns (outputs/all_droplets.csv:1) from per-droplet areas and centroids given in
+    label order; equivalent_diameter = sqrt(4 area / pi) (known answer: area 18224 -> 152.327, outputs/all_droplets.csv:2)."""
+    n = len(area)
+    if n == 0:
+        return pd.DataFrame()
+    area = np.asarray(area, dtype=np.int64)
+    df = pd.DataFrame({"label": np.arange(1, n + 1), "area": area, "equivalent_diameter": np.sqrt(4.0 * area / np.pi),
+                       "centroid-0": np.asarray(cen_row, dtype=np.float64), "centroid-1": np.asarray(cen_col, dtype=np.float64)})
+    if px_per_um is not None:
+        df["area_sqmicron"] = df["area"] / (px_per_um ** 2)
+        df["eq_diam_micron"] = df["equivalent_diameter"] / px_per_um
+    return df
+
+
 def quantify(bin_mask, min_area, px_per_um):
-    """Per-droplet table: label, area, equivalent_diameter, centroid-0/1 (+ micron columns)."""
+    """Per-droplet table: label, area, equivalent_diameter, centroid-0/1 (+ micron columns) -- CPU path (SciPy)."""
     from scipy import ndimage
-    lbl, n = ndimage.label(bin_mask)                     # 4-connectivity
+    lbl, n = ndimage.label(bin_mask)                     # 4-connectivity, labels in raster order of the first pixel
     if n:
         areas = np.bincount(lbl.ravel(), minlength=n + 1)
         keep = areas >= min_area
@@ -53,14 +73,16 @@ def quantify(bin_mask, min_area, px_per_um):
     if n == 0:
         return pd.DataFrame()
     idx = np.arange(1, n + 1)
-    area = np.bincount(lbl.ravel(), minlength=n + 1)[1:].astype(np.float64)
+    area = np.bincount(lbl.ravel(), minlength=n + 1)[1:]
     cen = np.array(ndimage.center_of_mass(np.ones_like(lbl), lbl, idx)).reshape(n, 2)
-    df = pd.DataFrame({"label": idx, "area": area, "equivalent_diameter": np.sqrt(4.0 * area / np.pi),
-                       "centroid-0": cen[:, 0], "centroid-1": cen[:, 1]})
-    if px_per_um is not None and not df.empty:
-        df["area_sqmicron"] = df["area"] / (px_per_um ** 2)
-        df["eq_diam_micron"] = df["equivalent_diameter"] / px_per_um
-    return df
+    return _droplet_table(area, cen[:, 0], cen[:, 1], px_per_um)
+
+
+def quantify_device(probs2d, thresh, out_hw, min_area, px_per_um):
+    """The same table from the probability map still on the HIP device; also returns the uint8 mask (host) for the PNG."""
+    from unet_dc_segmentation_amd.droplets import mask_and_droplets
+    mask, area, cy, cx = mask_and_droplets(probs2d, thresh, out_hw, min_area)
+    return mask.cpu().numpy(), _droplet_table(area, cy, cx, px_per_um)
 
 
 def _outline(mask):
@@ -72,13 +94,17 @@ def _outline(mask):
 def run_batch(tensors, meta, model, mask_dir, overlay_dir, thresh, min_area, px_per_um, per_image_rows, all_props):
     batch = torch.stack(tensors).to(DEVICE)
     probs = model(batch)                                 # sigmoid probabilities (model_2.py:80)
-    masks512 = (probs[:, 0] > thresh).to(torch.uint8).cpu().numpy()
+    on_device = probs.is_cuda
+    masks512 = None if on_device else (probs[:, 0] > thresh).to(torch.uint8).numpy()
     for i in range(len(tensors)):
         fpath, (oh, ow) = meta[i]
         name = Path(fpath).stem
-        mask = np.array(Image.fromarray(masks512[i]).resize((ow, oh), Image.NEAREST))
+        if on_device:
+            mask, df = quantify_device(probs[i, 0], thresh, (oh, ow), min_area, px_per_um)
+        else:
+            mask = resize_nearest_cv2(masks512[i], ow, oh)
+            df = quantify(mask, min_area, px_per_um)
         Image.fromarray(mask * 255).save(str(mask_dir / f"{name}_pred.png"))
-        df = quantify(mask, min_area, px_per_um)
         df.insert(0, "filename", Path(fpath).name) if not df.empty else None
         df.to_csv(mask_dir.parent / f"{name}_droplets.csv", index=False)
         all_props.append(df)

@@ -228,3 +228,15 @@ def test_fused_adam_cpu_formulas_match_torch():
     sda, sdb = oa.state_dict(), ob.state_dict()
     assert sda["state"].keys() == sdb["state"].keys() and set(sda["state"][0]) == set(sdb["state"][0])
     assert torch.allclose(sda["state"][0]["exp_avg"], sdb["state"][0]["exp_avg"], rtol=1e-6, atol=1e-10)
+
+
+def test_nearest_resize_restates_cv2_rule():
+    """cv2.resize(..., INTER_NEAREST) picks source index min(floor(d * src / dst), src - 1) (known answers computed by
+    hand: 4 -> 6 gives 0,0,1,2,2,3; 5 -> 2 gives 0,2); identity at equal size."""
+    from unet_dc_segmentation_amd.droplets import nearest_index, resize_nearest_cv2
+    assert nearest_index(6, 4).tolist() == [0, 0, 1, 2, 2, 3]
+    assert nearest_index(2, 5).tolist() == [0, 2]
+    m = np.arange(20, dtype=np.uint8).reshape(4, 5)
+    assert np.array_equal(resize_nearest_cv2(m, 5, 4), m)
+    up = resize_nearest_cv2(m, 10, 8)
+    assert up.shape == (8, 10) and np.array_equal(up[::2, ::2], m)

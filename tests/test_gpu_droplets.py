@@ -1,0 +1,111 @@
+"""GPU: droplet quantification kernels (csrc/ccl.hip) against the SciPy restatement of the reference's quantify()
+(/root/reference/quantify_droplets_batch.py:81-95): exact areas, centroids, label order; cv2's nearest-neighbour index
+rule; the strict `>` threshold.  Integer / byte work: the bar is bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference_table(mask, min_area):
+    import quantify_droplets_batch as q
+    return q.quantify(mask.astype(np.uint8), min_area, 3.45)
+
+
+def _device_table(probs, thresh, out_hw, min_area):
+    import quantify_droplets_batch as q
+    return q.quantify_device(torch.from_numpy(probs).cuda(), thresh, out_hw, min_area, 3.45)
+
+
+def _spiral(n):
+    """One long thin 4-connected spiral: the worst case for label propagation (a root thousands of hops away)."""
+    m = np.zeros((n, n), np.uint8)
+    y = x = 0
+    dy, dx = 0, 1
+    lo_y, hi_y, lo_x, hi_x = 0, n - 1, 0, n - 1
+    while lo_y <= hi_y and lo_x <= hi_x:
+        m[y, x] = 1
+        ny, nx = y + dy, x + dx
+        if not (lo_y <= ny <= hi_y and lo_x <= nx <= hi_x):
+            if (dy, dx) == (0, 1):
+                lo_y += 2
+            elif (dy, dx) == (1, 0):
+                hi_x -= 2
+            elif (dy, dx) == (0, -1):
+                hi_y -= 2
+            else:
+                lo_x += 2
+            dy, dx = dx, -dy
+            ny, nx = y + dy, x + dx
+            if not (lo_y - 2 <= ny <= hi_y + 2 and lo_x - 2 <= nx <= hi_x + 2) or m[min(max(ny, 0), n - 1), min(max(nx, 0), n - 1)]:
+                break
+        y, x = ny, nx
+        if not (0 <= y < n and 0 <= x < n):
+            break
+    return m
+
+
+@pytest.mark.parametrize("case", ["random", "discs", "spiral", "empty", "full", "checker"])
+@pytest.mark.parametrize("min_area", [1, 5])
+def test_ccl_table_matches_scipy(case, min_area):
+    rng = np.random.default_rng(7)
+    h, w = 384, 520
+    if case == "random":
+        m = (rng.random((h, w)) < 0.55).astype(np.uint8)         # near the percolation threshold: huge ragged components
+    elif case == "discs":
+        m = np.zeros((h, w), np.uint8)
+        yy, xx = np.mgrid[0:h, 0:w]
+        for _ in range(300):
+            cy, cx, r = rng.integers(0, h), rng.integers(0, w), rng.integers(1, 14)
+            m[(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = 1
+    elif case == "spiral":
+        m = np.zeros((h, w), np.uint8)
+        m[:384, :384] = _spiral(384)
+        m[10, 500] = 1                                        # plus a one-pixel object
+    elif case == "empty":
+        m = np.zeros((h, w), np.uint8)
+    elif case == "full":
+        m = np.ones((h, w), np.uint8)
+    else:
+        m = ((np.add.outer(np.arange(h), np.arange(w)) & 1) == 0).astype(np.uint8)   # 4-connectivity: every pixel its own object
+    probs = np.where(m > 0, 0.9, 0.1).astype(np.float32)
+    mask, df = _device_table(probs, 0.3, (h, w), min_area)
+    assert mask.dtype == np.uint8 and np.array_equal(mask, m)
+    ref = _reference_table(m, min_area)
+    assert len(df) == len(ref)
+    if len(ref):
+        assert list(df.columns) == list(ref.columns)
+        assert np.array_equal(df["label"].to_numpy(), ref["label"].to_numpy())
+        assert np.array_equal(df["area"].to_numpy(), ref["area"].to_numpy())
+        np.testing.assert_allclose(df["centroid-0"].to_numpy(), ref["centroid-0"].to_numpy(), rtol=0, atol=1e-9)
+        np.testing.assert_allclose(df["centroid-1"].to_numpy(), ref["centroid-1"].to_numpy(), rtol=0, atol=1e-9)
+        np.testing.assert_allclose(df["equivalent_diameter"].to_numpy(), ref["equivalent_diameter"].to_numpy(), rtol=1e-15)
+
+
+@pytest.mark.parametrize("out_hw", [(512, 512), (276, 408), (1037, 1388), (97, 33)])
+def test_threshold_is_strict_and_resize_follows_cv2_rule(out_hw):
+    """mask = cv2.resize((p > thresh).astype(uint8), (ow, oh), INTER_NEAREST): strict compare on the fp32 value
+    (a probability exactly at the threshold is background) and source index min(floor(d * src / dst), src - 1)."""
+    from unet_dc_segmentation_amd.droplets import mask_and_droplets, resize_nearest_cv2
+    g = torch.Generator().manual_seed(5)
+    p = torch.rand(512, 512, generator=g)
+    thresh = float(np.float32(0.3))
+    p[::7, ::5] = thresh                                       # exactly at the threshold
+    p[3::11, 2::13] = float(np.nextafter(np.float32(0.3), np.float32(1)))   # one ulp above
+    oh, ow = out_hw
+    mask, area, cy, cx = mask_and_droplets(p.cuda(), thresh, (oh, ow), 1)
+    ref512 = (p.numpy() > np.float32(0.3)).astype(np.uint8)
+    ref = resize_nearest_cv2(ref512, ow, oh)
+    assert np.array_equal(mask.cpu().numpy(), ref)
+    assert int(area.sum()) == int(ref.sum())
+
+
+def test_more_droplets_than_the_first_output_capacity():
+    """The output arrays are sized for 65536 droplets; a mask with more (isolated pixels) takes the second pass."""
+    from unet_dc_segmentation_amd.droplets import mask_and_droplets
+    m = np.zeros((1024, 1024), np.float32)
+    m[::2, ::2] = 1.0                                          # 262144 one-pixel objects
+    mask, area, cy, cx = mask_and_droplets(torch.from_numpy(m).cuda(), 0.5, (1024, 1024), 1)
+    assert len(area) == 262144 and int(area.min()) == 1 and int(area.max()) == 1
+    assert cy[0] == 0 and cx[1] == 2 and cy[512] == 2 and cx[512] == 0          # raster order

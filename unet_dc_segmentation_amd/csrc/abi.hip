@@ -351,4 +351,19 @@ int unetdc_channel_sum(const void* x, int ldx, float* out, void* workspace, int6
   return launch_channel_sum(x, ldx, out, workspace, (long)workspace_bytes, (long)npixels, c, dtype, (hipStream_t)s);
 }
 
+int unetdc_mask_from_probs(const float* probs, int ph, int pw, float thresh, uint8_t* mask, int oh, int ow,
+                           unetdc_stream_t s) {
+  return launch_mask_from_probs(probs, ph, pw, thresh, mask, oh, ow, (hipStream_t)s);
+}
+
+int64_t unetdc_ccl_workspace(int h, int w) { return ccl_workspace_bytes(h, w); }
+
+int unetdc_ccl_stats(const uint8_t* mask, int h, int w, int min_area, void* workspace, int64_t workspace_bytes,
+                     int32_t* out_count, int32_t* out_area, int64_t* out_sumy, int64_t* out_sumx, int32_t* out_root,
+                     int max_out, unetdc_stream_t s) {
+  return launch_ccl_stats(mask, h, w, min_area, workspace, (long)workspace_bytes, out_count, out_area,
+                          reinterpret_cast<long long*>(out_sumy), reinterpret_cast<long long*>(out_sumx), out_root, max_out,
+                          (hipStream_t)s);
+}
+
 }  // extern "C"

@@ -120,6 +120,14 @@ long channel_sum_workspace_bytes(long P, int C);
 int launch_channel_sum(const void* x, int ldx, float* out, void* workspace, long workspace_bytes, long P, int C,
                        int dtype, hipStream_t stream);
 
+// ccl.hip: droplet quantification
+int launch_mask_from_probs(const float* probs, int ph, int pw, float thresh, unsigned char* mask, int oh, int ow,
+                           hipStream_t stream);
+long ccl_workspace_bytes(int h, int w);
+int launch_ccl_stats(const unsigned char* mask, int h, int w, int min_area, void* workspace, long workspace_bytes,
+                     int* out_count, int* out_area, long long* out_sumy, long long* out_sumx, int* out_root, int max_out,
+                     hipStream_t stream);
+
 long loss_workspace_bytes(int nimg, long hw);
 int launch_loss_fwd(const float* p, const float* t, float* loss_out, float* coef, void* workspace, long workspace_bytes,
                     int nimg, long hw, float alpha, float gamma, float ratio, float smooth, hipStream_t stream);

@@ -1,0 +1,52 @@
+"""Droplet quantification on the HIP device (csrc/ccl.hip): probabilities -> mask at the original image size -> 4-connected
+components -> the per-droplet table of the reference's ``quantify()`` (/root/reference/quantify_droplets_batch.py:81-95).
+
+Only the uint8 mask (needed for the PNG the script writes) and three integers per droplet cross PCIe; the reference
+copies every fp32 probability map to the host, labels it twice with scikit-image and walks ``np.unique`` in Python.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def nearest_index(dst, src):
+    """Source index of each destination index under cv2.resize(..., INTER_NEAREST): min(floor(d * src / dst), src - 1)."""
+    return np.minimum(np.floor(np.arange(dst) * (src / dst)).astype(np.int64), src - 1)
+
+
+def resize_nearest_cv2(mask, ow, oh):
+    """numpy restatement of cv2.resize(mask, (ow, oh), interpolation=cv2.INTER_NEAREST) (used where cv2 is absent)."""
+    return mask[nearest_index(oh, mask.shape[0])[:, None], nearest_index(ow, mask.shape[1])[None, :]]
+
+
+def mask_and_droplets(probs2d, thresh, out_hw, min_area, max_droplets=1 << 16):
+    """probs2d: [H, W] fp32 probabilities on the HIP device.  Returns (mask uint8 [oh, ow] DEVICE tensor,
+    area int64 [n], centroid_row float64 [n], centroid_col float64 [n]) -- droplets in the reference's label order."""
+    if not probs2d.is_cuda or probs2d.dtype != torch.float32:
+        raise _lib.UnetdcError("mask_and_droplets needs an fp32 tensor on the HIP device")
+    probs2d = probs2d.contiguous()
+    ph, pw = probs2d.shape
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    dev = probs2d.device
+    s = torch.cuda.current_stream().cuda_stream
+    mask = torch.empty(oh, ow, dtype=torch.uint8, device=dev)
+    _lib.call("unetdc_mask_from_probs", probs2d.data_ptr(), ph, pw, float(thresh), mask.data_ptr(), oh, ow, s)
+    nbytes = _lib.load().unetdc_ccl_workspace(oh, ow)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    cap = int(min(max_droplets, oh * ow))
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    area = torch.empty(cap, dtype=torch.int32, device=dev)
+    sy = torch.empty(cap, dtype=torch.int64, device=dev)
+    sx = torch.empty(cap, dtype=torch.int64, device=dev)
+    _lib.call("unetdc_ccl_stats", mask.data_ptr(), oh, ow, int(max(min_area, 1)), ws.data_ptr(), nbytes, count.data_ptr(),
+              area.data_ptr(), sy.data_ptr(), sx.data_ptr(), None, cap, s)
+    n = int(count.item())
+    if n > cap:                                   # more droplets than the output capacity: run again with room for all
+        return mask_and_droplets(probs2d, thresh, out_hw, min_area, max_droplets=n)
+    a = area[:n].cpu().numpy().astype(np.int64)
+    cy = sy[:n].cpu().numpy().astype(np.float64) / np.maximum(a, 1)
+    cx = sx[:n].cpu().numpy().astype(np.float64) / np.maximum(a, 1)
+    return mask, a, cy, cx
