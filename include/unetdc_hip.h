@@ -228,6 +228,21 @@ int unetdc_ccl_stats(const uint8_t* mask, int h, int w, int min_area, void* work
                      int32_t* out_count, int32_t* out_area, int64_t* out_sumy, int64_t* out_sumx, int32_t* out_root,
                      int max_out, unetdc_stream_t s);
 
+/* ---- input preprocessing: /root/reference/utils/data_loader.py:11-24, quantify_droplets_batch.py:40-46
+ * unetdc_rolling_ball_u8: per channel of an interleaved HWC uint8 image: background = opening with the ksize x ksize
+ *   ellipse of cv2.getStructuringElement (dilate(erode(.)), pixels outside the image ignored), dst = normalize_minmax(
+ *   saturate(src - background)) to 0..255 (scale/shift in double, applied in float, round half to even).  ksize <= 128,
+ *   channels <= 4.  dst may not alias src.
+ * unetdc_resize_linear_u8_to_chw_f32: OpenCV's 8-bit INTER_LINEAR resize to (dh, dw), / 255, HWC -> CHW float32 (the
+ *   network input layout).  xofs[dw] / yofs[dh]: source index of the first tap (x already clamped to [0, w-1]),
+ *   xcoef[dw][2] / ycoef[dh][2]: the 11-bit coefficients (utils/data_loader.py:linear_tables builds them). */
+int64_t unetdc_rolling_ball_workspace(int h, int w, int channels);
+int unetdc_rolling_ball_u8(const uint8_t* src_hwc, uint8_t* dst_hwc, int h, int w, int channels, int ksize, void* workspace,
+                           int64_t workspace_bytes, unetdc_stream_t s);
+int unetdc_resize_linear_u8_to_chw_f32(const uint8_t* src_hwc, int h, int w, int channels, float* dst_chw, int dh, int dw,
+                                       const int32_t* xofs, const int16_t* xcoef, const int32_t* yofs, const int16_t* ycoef,
+                                       unetdc_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

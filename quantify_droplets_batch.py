@@ -41,6 +41,9 @@ def load_model(ckpt, dtype="f32"):
 def preprocess(path, background_radius):
     im = np.array(Image.open(path).convert("RGB"))
     oh, ow = im.shape[:2]
+    if DEVICE == "cuda":                                 # rolling ball + resize + /255 + CHW on the GPU (csrc/preprocess.hip)
+        from unet_dc_segmentation_amd.preprocess import preprocess_device
+        return preprocess_device(im, background_radius, IMG_SIZE, DEVICE), (oh, ow)
     im = rolling_ball_correction_rgb(im, background_radius)
     im = resize_image(im, IMG_SIZE).astype(np.float32) / 255.0
     return torch.from_numpy(im).permute(2, 0, 1), (oh, ow)

@@ -240,3 +240,44 @@ def test_nearest_resize_restates_cv2_rule():
     assert np.array_equal(resize_nearest_cv2(m, 5, 4), m)
     up = resize_nearest_cv2(m, 10, 8)
     assert up.shape == (8, 10) and np.array_equal(up[::2, ::2], m)
+
+
+def test_opencv_restatements_known_answers():
+    """numpy restatements of the OpenCV operators (the CPU preprocessing path and the yardstick of csrc/preprocess.hip):
+    ellipse element of getStructuringElement (5x5 and the 50x50 of the reference), erosion / dilation against a brute-force
+    evaluation of the definition, min-max normalisation rounding, identity and 2x bilinear resize."""
+    from utils.data_loader import (ellipse_spans, morph_cv2, normalize_minmax_u8, resize_linear_cv2_u8,
+                                   rolling_ball_correction_rgb)
+    # cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (5, 5)) = rows 00100 / 11111 / 11111 / 11111 / 00100
+    assert ellipse_spans(5) == [(2, 3), (0, 5), (0, 5), (0, 5), (2, 3)]
+    sp = ellipse_spans(50)
+    assert sp[0] == (25, 26) and sp[25] == (0, 50) and sp[49] == (18, 33) and len(sp) == 50
+    rng = np.random.default_rng(0)
+    img = (rng.random((40, 47)) * 255).astype(np.uint8)
+
+    def brute(plane, k, is_max):
+        h, w = plane.shape
+        r = k // 2
+        out = np.zeros_like(plane)
+        for y in range(h):
+            for x in range(w):
+                vals = []
+                for i, (j1, j2) in enumerate(ellipse_spans(k)):
+                    yy = y + i - r
+                    lo, hi = max(x + j1 - r, 0), min(x + j2 - r, w)
+                    if 0 <= yy < h and hi > lo:
+                        vals.append(plane[yy, lo:hi].max() if is_max else plane[yy, lo:hi].min())
+                out[y, x] = (max(vals) if is_max else min(vals)) if vals else (0 if is_max else 255)
+        return out
+    for k in (1, 2, 5, 8):
+        for is_max in (False, True):
+            assert np.array_equal(morph_cv2(img, k, is_max), brute(img, k, is_max)), (k, is_max)
+    a = np.array([[10, 20, 30, 137]], np.uint8)
+    assert normalize_minmax_u8(a).tolist() == [[0, 20, 40, 255]]            # 10 * 255/127 = 20.08, 20 * ... = 40.16
+    assert not normalize_minmax_u8(np.full((3, 3), 7, np.uint8)).any()
+    big = (rng.random((33, 21, 3)) * 255).astype(np.uint8)
+    assert np.array_equal(resize_linear_cv2_u8(big, 21, 33), big)
+    const = np.full((10, 10), 200, np.uint8)
+    assert (resize_linear_cv2_u8(const, 23, 17) == 200).all()
+    rb = rolling_ball_correction_rgb(big, 5)
+    assert rb.shape == big.shape and rb.dtype == np.uint8 and rb.max() == 255 and rb.min() == 0

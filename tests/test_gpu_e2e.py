@@ -444,7 +444,7 @@ def test_quantify_cli_on_gpu_512(tmp_path):
     model = UNetDC(3, 1)
     recipe.perturb_bn(model.state_dict(), 5)
     # calibrate the head bias so that the mask is about half ones (random init is all-ones at 0.3)
-    xs = torch.stack([q.preprocess(img_dir / f"im{i}.png", 15)[0] for i in range(4)])
+    xs = torch.stack([q.preprocess(img_dir / f"im{i}.png", 15)[0] for i in range(4)]).cpu()     # GPU preprocessing: bit-exact vs the CPU path (test_gpu_preprocess.py)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     with torch.no_grad():
         _, z = otc.unet_forward(xs, sd, dict(model.DILATIONS), train=False, return_logits=True)

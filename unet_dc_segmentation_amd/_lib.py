@@ -58,6 +58,9 @@ SIGNATURES = {
     "unetdc_conv3x3_dgrad_colsum": (I, [P, I, P, P, I, P, I, I, P, L, I, I, I, I, I, I, I, P]),
     "unetdc_channel_sum_workspace": (L, [L, I]),
     "unetdc_channel_sum": (I, [P, I, P, P, L, L, I, I, P]),
+    "unetdc_rolling_ball_workspace": (L, [I, I, I]),
+    "unetdc_rolling_ball_u8": (I, [P, P, I, I, I, I, P, L, P]),
+    "unetdc_resize_linear_u8_to_chw_f32": (I, [P, I, I, I, P, I, I, P, P, P, P, P]),
     "unetdc_mask_from_probs": (I, [P, I, I, F, P, I, I, P]),
     "unetdc_ccl_workspace": (L, [I, I]),
     "unetdc_ccl_stats": (I, [P, I, I, I, P, L, P, P, P, P, P, I, P]),

@@ -366,4 +366,17 @@ int unetdc_ccl_stats(const uint8_t* mask, int h, int w, int min_area, void* work
                           (hipStream_t)s);
 }
 
+int64_t unetdc_rolling_ball_workspace(int h, int w, int channels) { return rolling_ball_workspace_bytes(h, w, channels); }
+
+int unetdc_rolling_ball_u8(const uint8_t* src_hwc, uint8_t* dst_hwc, int h, int w, int channels, int ksize, void* workspace,
+                           int64_t workspace_bytes, unetdc_stream_t s) {
+  return launch_rolling_ball(src_hwc, dst_hwc, h, w, channels, ksize, workspace, (long)workspace_bytes, (hipStream_t)s);
+}
+
+int unetdc_resize_linear_u8_to_chw_f32(const uint8_t* src_hwc, int h, int w, int channels, float* dst_chw, int dh, int dw,
+                                       const int32_t* xofs, const int16_t* xcoef, const int32_t* yofs, const int16_t* ycoef,
+                                       unetdc_stream_t s) {
+  return launch_resize_linear_chw(src_hwc, h, w, channels, dst_chw, dh, dw, xofs, xcoef, yofs, ycoef, (hipStream_t)s);
+}
+
 }  // extern "C"

@@ -128,6 +128,13 @@ int launch_ccl_stats(const unsigned char* mask, int h, int w, int min_area, void
                      int* out_count, int* out_area, long long* out_sumy, long long* out_sumx, int* out_root, int max_out,
                      hipStream_t stream);
 
+// preprocess.hip: rolling-ball correction + bilinear resize to the network input
+long rolling_ball_workspace_bytes(int h, int w, int cn);
+int launch_rolling_ball(const unsigned char* src, unsigned char* dst, int h, int w, int cn, int k, void* workspace,
+                        long workspace_bytes, hipStream_t stream);
+int launch_resize_linear_chw(const unsigned char* src, int h, int w, int cn, float* dst, int dh, int dw, const int* xofs,
+                             const short* xa, const int* yofs, const short* ya, hipStream_t stream);
+
 long loss_workspace_bytes(int nimg, long hw);
 int launch_loss_fwd(const float* p, const float* t, float* loss_out, float* coef, void* workspace, long workspace_bytes,
                     int nimg, long hw, float alpha, float gamma, float ratio, float smooth, hipStream_t stream);

@@ -2,7 +2,8 @@
 
 Off the hot path (CPU image prep): provided so the kept entry points run
 end to end.  cv2 / albumentations are optional; without them the same operations run on
-PIL + SciPy (grey opening with an elliptical footprint == cv2.MORPH_OPEN with MORPH_ELLIPSE).
+numpy restatements of the OpenCV operators (ellipse element, opening, saturating subtract, min-max
+normalise, 8-bit bilinear resize) written from OpenCV's definitions.
 Reference lines: rolling_ball_correction_rgb :11-24, SegmentationDataset :26-76.
 ``transform`` may follow the albumentations protocol (keyword call, dict result -- what the reference passes)
 or be a plain ``(img, mask) -> (img, mask)`` callable; :class:`TrainAugment` restates the reference's
@@ -23,16 +24,69 @@ except Exception:                       # pragma: no cover - cv2 absent in the b
     cv2 = None
 
 
-def _ellipse(radius):
-    """Elliptical structuring element of size (radius, radius), like cv2.getStructuringElement."""
-    r = max(int(radius), 1)
-    yy, xx = np.mgrid[0:r, 0:r]
-    c = (r - 1) / 2.0
-    return (((yy - c) / max(c, 0.5)) ** 2 + ((xx - c) / max(c, 0.5)) ** 2) <= 1.0 + 1e-9
+# ---------------------------------------------------------------------------------------------------------------------
+# OpenCV's operators restated on numpy (cv2 is not installed in the build image).  These functions are the CPU path of
+# the entry points AND the yardstick of the GPU preprocessing kernels (unet_dc_segmentation_amd/csrc/preprocess.hip,
+# bit-exact against them).  Against cv2 itself they are "parity unpinned": written from OpenCV's documented definitions
+# and source structure, not checked against a cv2 run.
+def ellipse_spans(k):
+    """Row spans [j1, j2) of cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (k, k)): r = c = k // 2,
+    dx = round(c * sqrt(1 - dy^2 / r^2)), anchor (k // 2, k // 2)."""
+    r = c = k // 2
+    inv_r2 = 1.0 / (r * r) if r else 0.0
+    spans = []
+    for i in range(k):
+        dy = i - r
+        if abs(dy) <= r:
+            dx = int(np.rint(c * np.sqrt((r * r - dy * dy) * inv_r2)))
+            spans.append((max(c - dx, 0), min(c + dx + 1, k)))
+        else:
+            spans.append((0, 0))
+    return spans
+
+
+def _window_reduce(a, width, op, ident):
+    """out[..., x] = op over a[..., x : x + width] (a already padded on the right by >= width - 1 with `ident`)."""
+    if width == 1:
+        return a
+    p = 1
+    m = a
+    while 2 * p <= width:                       # doubling: m[x] = op(a[x : x + p])
+        m2 = np.full_like(m, ident)
+        m2[..., : m.shape[-1] - p] = op(m[..., : m.shape[-1] - p], m[..., p:])
+        m, p = m2, 2 * p
+    if p == width:
+        return m
+    out = np.full_like(m, ident)
+    sh = width - p
+    out[..., : m.shape[-1] - sh] = op(m[..., : m.shape[-1] - sh], m[..., sh:])
+    return out
+
+
+def morph_cv2(plane, k, is_max):
+    """cv2.erode / cv2.dilate of a 2-D uint8 array with the k x k ellipse: dst(y, x) = min|max over element pixels (i, j) of
+    src(y + i - r, x + j - r); pixels outside the image do not take part (OpenCV's default border value)."""
+    h, w = plane.shape
+    r = k // 2
+    ident = 0 if is_max else 255
+    op = np.maximum if is_max else np.minimum
+    pad = np.full((h + k, w + 2 * k), ident, dtype=np.uint8)
+    pad[r:r + h, r:r + w] = plane               # pad[y + r, x + r] = src(y, x)
+    out = np.full((h, w), ident, dtype=np.uint8)
+    cache = {}
+    for i, (j1, j2) in enumerate(ellipse_spans(k)):
+        if j2 <= j1:
+            continue
+        if (j1, j2) not in cache:               # horizontal reduction over columns x + j - r, j in [j1, j2), for every row
+            red = _window_reduce(pad, j2 - j1, op, ident)
+            cache[(j1, j2)] = red[:, j1:j1 + w]     # column x + j1 - r of src = pad column x + j1
+        out = op(out, cache[(j1, j2)][i:i + h])     # row y + i - r of src = pad row y + i
+    return out
 
 
 def rolling_ball_correction_rgb(image, radius=50):
-    """Per channel: subtract the morphological opening (background), stretch to 0..255."""
+    """Per channel: subtract the morphological opening (background), stretch to 0..255
+    (/root/reference/utils/data_loader.py:11-24).  `radius` is the SIZE of the elliptical element, as in the reference."""
     if cv2 is not None:
         kernel = cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (radius, radius))
         chans = []
@@ -40,27 +94,71 @@ def rolling_ball_correction_rgb(image, radius=50):
             bg = cv2.morphologyEx(ch, cv2.MORPH_OPEN, kernel)
             chans.append(cv2.normalize(cv2.subtract(ch, bg), None, 0, 255, cv2.NORM_MINMAX))
         return cv2.merge(chans)
-    from scipy import ndimage
-    fp = _ellipse(radius)
     out = np.empty_like(image)
+    k = int(radius)
     for c in range(image.shape[2]):
-        ch = image[..., c]
-        bg = ndimage.grey_opening(ch, footprint=fp, mode="nearest")
-        corr = np.clip(ch.astype(np.int32) - bg.astype(np.int32), 0, 255).astype(np.float32)
-        lo, hi = float(corr.min()), float(corr.max())
-        out[..., c] = np.round((corr - lo) * (255.0 / (hi - lo))).astype(image.dtype) if hi > lo else 0
+        ch = np.ascontiguousarray(image[..., c])
+        bg = morph_cv2(morph_cv2(ch, k, False), k, True)           # MORPH_OPEN = dilate(erode(.)) with the same element
+        corr = np.clip(ch.astype(np.int16) - bg.astype(np.int16), 0, 255).astype(np.uint8)      # cv2.subtract saturates
+        out[..., c] = normalize_minmax_u8(corr)
     return out
 
 
+def normalize_minmax_u8(a):
+    """cv2.normalize(a, None, 0, 255, cv2.NORM_MINMAX) on uint8: scale / shift formed in double, applied in float32
+    (separate multiply and add), rounded half to even, saturated."""
+    smin, smax = float(a.min()), float(a.max())
+    scale = 255.0 * (1.0 / (smax - smin) if (smax - smin) > np.finfo(np.float64).eps else 0.0)
+    shift = 0.0 - smin * scale
+    v = a.astype(np.float32) * np.float32(scale) + np.float32(shift)
+    return np.clip(np.rint(v), 0, 255).astype(np.uint8)
+
+
+def linear_tables(src, dst):
+    """Source index of the first tap and the two 11-bit coefficients of OpenCV's 8-bit INTER_LINEAR per destination index."""
+    scale = src / dst
+    ofs = np.empty(dst, dtype=np.int32)
+    coef = np.empty((dst, 2), dtype=np.int16)
+    for d in range(dst):
+        f = (d + 0.5) * scale - 0.5
+        s = int(np.floor(f))
+        f -= s
+        ofs[d] = s
+        coef[d] = (int(np.rint(np.float32(1.0 - np.float32(f)) * 2048)), int(np.rint(np.float32(f) * 2048)))
+    return ofs, coef
+
+
+def resize_linear_cv2_u8(img, dw, dh):
+    """cv2.resize(img, (dw, dh)) with the default INTER_LINEAR on uint8 HxWxC (or HxW): fixed-point coefficients (11 bits),
+    horizontal pass in int32, vertical pass ((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2."""
+    a = img if img.ndim == 3 else img[..., None]
+    h, w = a.shape[:2]
+    xo, xa = linear_tables(w, dw)
+    yo, ya = linear_tables(h, dh)
+    neg, top = xo < 0, xo >= w - 1                 # left of the first / right of the last source pixel: one tap, weight 1
+    xa = xa.copy()
+    xa[neg | top] = (2048, 0)
+    x0 = np.clip(xo, 0, w - 1)
+    x1 = np.minimum(x0 + 1, w - 1)
+    y0, y1 = np.clip(yo, 0, h - 1), np.clip(yo + 1, 0, h - 1)
+    s = a.astype(np.int32)
+    rows = s[:, x0] * xa[:, 0].astype(np.int32)[None, :, None] + s[:, x1] * xa[:, 1].astype(np.int32)[None, :, None]
+    r0, r1 = rows[y0], rows[y1]
+    b0, b1 = ya[:, 0].astype(np.int32)[:, None, None], ya[:, 1].astype(np.int32)[:, None, None]
+    v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2
+    out = np.clip(v, 0, 255).astype(np.uint8)
+    return out if img.ndim == 3 else out[..., 0]
+
+
 def resize_image(arr, size, nearest=False):
-    """Resize HxW(xC) uint8/float array to (size, size)."""
+    """Resize HxW(xC) uint8 array to (size, size): bilinear like the reference's calls end up doing (their third positional
+    argument of cv2.resize is `dst`, so the interpolation stays at its INTER_LINEAR default), or nearest for masks."""
     if cv2 is not None:
-        return cv2.resize(arr, (size, size), interpolation=cv2.INTER_NEAREST if nearest else cv2.INTER_AREA)
-    mode = Image.NEAREST if nearest else Image.BILINEAR
-    if arr.ndim == 2:
-        return np.array(Image.fromarray(arr).resize((size, size), mode))
-    return np.stack([np.array(Image.fromarray(arr[..., c]).resize((size, size), mode))
-                     for c in range(arr.shape[2])], axis=-1)
+        return cv2.resize(arr, (size, size), interpolation=cv2.INTER_NEAREST if nearest else cv2.INTER_LINEAR)
+    if nearest:
+        from unet_dc_segmentation_amd.droplets import resize_nearest_cv2
+        return resize_nearest_cv2(arr, size, size)
+    return resize_linear_cv2_u8(arr, size, size)
 
 
 class SegmentationDataset(Dataset):
