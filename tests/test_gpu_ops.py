@@ -110,6 +110,26 @@ def test_wgrad_tap_fused(dtype, case):
     assert rel(dw, gw_ref) < TOL_W[dtype], rel(dw, gw_ref)
 
 
+@pytest.mark.parametrize("case", [(2, 32, 32, 256, 256, 16), (1, 16, 24, 256, 512, 8), (3, 24, 40, 512, 256, 16),
+                                  (8, 32, 32, 512, 1024, 16)])
+def test_wgrad_valid_rectangles(case):
+    """Strongly dilated layers (the bottleneck: d = 16 on 32 x 32) in bf16: routed to wgrad_rect.hip, where every tap sums
+    over its valid output rectangle only and K is cut into equal units (centre tap 4, edge taps 2, corner taps 1 for the
+    square case; ragged rectangles and a unit that does not divide the lists in the other cases)."""
+    n, h, w, cin, cout, d = case
+    g = gen(6)
+    x = G.quant(torch.randn(n, cin, h, w, generator=g), "bf16")
+    dy = G.quant(torch.randn(n, cout, h, w, generator=g), "bf16")
+    wr = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    gw_ref, = torch.autograd.grad(F.conv2d(x, wr, None, padding=d, dilation=d), wr, dy)
+    xv = G.to_nhwc(x, "bf16", ld=cin + 64, off=64)
+    dw = G.conv3x3_wgrad(xv, G.to_nhwc(dy, "bf16"), n, h, w, cin, cout, d, "bf16")
+    assert _lib.load().unetdc_last_kernel().decode().startswith("wgrad_rect_kernel")
+    assert rel(dw.cpu(), gw_ref) < TOL_W["bf16"], rel(dw.cpu(), gw_ref)
+    dw2 = G.conv3x3_wgrad(xv, G.to_nhwc(dy, "bf16"), n, h, w, cin, cout, d, "bf16")
+    assert torch.equal(dw, dw2)                            # fixed summation order: bitwise reproducible
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_wgrad_many_pixels_ksplit(dtype):
     """K (pixels) large enough that several K-slices and a ragged last slice are exercised."""

@@ -184,7 +184,12 @@ int64_t unetdc_conv3x3_wgrad_workspace(int n, int h, int w, int cin, int cout, i
   // the tap-fused kernel may be chosen (launch_wgrad decides with wgrad_fused_supported; the query returns 0 for
   // shapes that kernel never takes, so the same condition governs both sides)
   const long f = wgrad_fused_workspace_bytes(n, h, w, cout, cin, dtype);
-  return f > b ? f : b;
+  if (f > b) b = f;
+  for (int d = 1; d <= 64; d *= 2) {          // the valid-rectangle kernel (strongly dilated layers); dilation is not an argument here
+    const long r = wgrad_rect_workspace_bytes(n, h, w, cout, cin, d);
+    if (r > b) b = r;
+  }
+  return b;
 }
 
 int unetdc_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace,

@@ -43,11 +43,25 @@ __device__ __forceinline__ Epi16Consts epi16_consts(const IgemmParams& p, int cc
   return c;
 }
 
-// TMT M-tiles of 16 rows x 4 N-tiles of 16 channels per wave -> global memory (bf16); constants preloaded
-template <int MODE, int TMT>
+// the saved conv outputs MODE_BNBWD reads, fetched ahead of the epilogue (persistent kernels issue this a few taps before
+// the last MFMA of an item so that the HBM latency is not exposed)
+template <int TMT>
+__device__ __forceinline__ void epi16_prefetch_y(const IgemmParams& p, const unsigned (&yoff)[TMT], unsigned yrow_bytes,
+                                                 u32x2 (&ypre)[TMT][4]) {
+  const __amdgpu_buffer_rsrc_t yrr = whole_buffer(p.bn_y);
+#pragma unroll
+  for (int i = 0; i < TMT; ++i)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) ypre[i][v] = __builtin_amdgcn_raw_buffer_load_b64(yrr, yoff[i], (unsigned)v * yrow_bytes, 0);
+}
+
+// TMT M-tiles of 16 rows x 4 N-tiles of 16 channels per wave -> global memory (bf16); constants preloaded;
+// YPRE: MODE_BNBWD takes the saved conv outputs from `ypre` (epi16_prefetch_y) instead of loading them here
+template <int MODE, int TMT, bool YPRE = false>
 __device__ __forceinline__ void epilogue16c(const IgemmParams& p, f32x4 (&acc)[TMT][4], const bool (&tile_ok)[TMT],
                                             const unsigned (&voff)[TMT], unsigned row_bytes, const unsigned (&yoff)[TMT],
-                                            unsigned yrow_bytes, const Epi16Consts& kc, float (&s)[4], float (&q)[4]) {
+                                            unsigned yrow_bytes, const Epi16Consts& kc, float (&s)[4], float (&q)[4],
+                                            const u32x2 (*ypre)[4] = nullptr) {
   const __amdgpu_buffer_rsrc_t orr = whole_buffer(p.out);
   const __amdgpu_buffer_rsrc_t yrr = whole_buffer(MODE == MODE_BNBWD ? p.bn_y : p.out);
   const float (&k0)[4] = kc.k0, (&k1)[4] = kc.k1, (&mu)[4] = kc.mu, (&rs)[4] = kc.rs;
@@ -55,7 +69,12 @@ __device__ __forceinline__ void epilogue16c(const IgemmParams& p, f32x4 (&acc)[T
 #pragma unroll
   for (int i0 = 0; i0 < TMT; i0 += GRP) {
     u32x2 yraw[GRP][4];
-    if (MODE == MODE_BNBWD) {
+    if (MODE == MODE_BNBWD && YPRE) {
+#pragma unroll
+      for (int ii = 0; ii < GRP; ++ii)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) yraw[ii][v] = ypre[i0 + ii][v];
+    } else if (MODE == MODE_BNBWD) {
 #pragma unroll
       for (int ii = 0; ii < GRP; ++ii)
 #pragma unroll

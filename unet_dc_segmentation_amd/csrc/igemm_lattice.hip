@@ -199,7 +199,28 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
   };
 
   // one tap: fragments of both 32-channel halves, MT*4*2 MFMAs
+  // (the 4-wave BatchNorm-backward variant also carries the prefetched saved outputs: there the two halves take turns
+  //  in ONE fragment register set, everywhere else both halves are read up front)
+  constexpr bool SPLIT_FRAGS = (MODE == MODE_BNBWD && NW == 4);
   auto compute_tap = [&](int ky, int kx, int stage, const int (&ab)[3][2]) {
+    if (SPLIT_FRAGS) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        u32x4 fa[MT], fb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = ld16(smem + boff[g] + stage * WST + j * 16 * 128);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[i] = ld16(smem + ab[kx][g] + ((i >> 1) + ky) * (LPW * 128) + (i & 1) * (16 * 128));
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
+                                                                acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    }
     u32x4 fa[2][MT], fb[2][4];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
@@ -222,6 +243,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
   // ---- epilogue of one item -----------------------------------------------------------------------------------------------
   const unsigned ldob = (unsigned)(p.ldo * 2), ldyb = (unsigned)(p.bn_ldy * 2);
   const int xb = (rb == 0) ? 0 : (rb == 1 ? 1 : (rb == 2 ? 9 : 8));          // pixel of accumulator row 4*rb + v = xb + 2v
+  // MODE_BNBWD: the consumer stage's saved conv outputs of this item, fetched YT taps before the item's last MFMA.  They
+  // sit in the VM queue between the weight DMAs: the counted waits of the two taps after the fetch leave them in flight
+  // (+NY), from the third tap on an in-order wait would require them -- so the fetch goes at tap 6 of the last chunk.
+  constexpr int YT = 6, NY = (MODE == MODE_BNBWD) ? MT * 4 : 0;
+  u32x2 ypre[MT][4];
+  auto item_offsets = [&](const Item& it, unsigned (&voff)[MT], unsigned (&yoff)[MT]) {
+    const int col = it.nblk * BN + wn * 64 + 4 * c16;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int gm = wm * MT + i;                                            // M tile of the workgroup: row gm >> 1, half gm & 1
+      const int Y = (it.ly0 + (gm >> 1)) * d + it.phy, X = (it.lx0 + 16 * (gm & 1) + xb) * d + it.phx;
+      const unsigned pix = (unsigned)((it.img * p.Ho + Y) * p.Wo + X);
+      voff[i] = pix * ldob + (unsigned)(col * 2);
+      yoff[i] = pix * ldyb + (unsigned)(col * 2);
+    }
+  };
   Epi16Consts ec;
   auto load_consts = [&](int nblk) {
     ec = epi16_consts<MODE>(p, nblk * BN + wn * 64 + 4 * c16);
@@ -233,19 +270,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
   auto epilogue = [&](const Item& it) {
     bool tile_ok[MT];
     unsigned voff[MT], yoff[MT];
-    const int col = it.nblk * BN + wn * 64 + 4 * c16;
+    item_offsets(it, voff, yoff);
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int gm = wm * MT + i;                                            // M tile of the workgroup: row gm >> 1, half gm & 1
-      const int Y = (it.ly0 + (gm >> 1)) * d + it.phy, X = (it.lx0 + 16 * (gm & 1) + xb) * d + it.phx;
-      const unsigned pix = (unsigned)((it.img * p.Ho + Y) * p.Wo + X);
-      tile_ok[i] = true;
-      voff[i] = pix * ldob + (unsigned)(col * 2);
-      yoff[i] = pix * ldyb + (unsigned)(col * 2);
-    }
+    for (int i = 0; i < MT; ++i) tile_ok[i] = true;
     float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
     const unsigned rbytes = 2u * (unsigned)d * ldob, yrbytes = 2u * (unsigned)d * ldyb;   // accumulator rows are 2 lattice pixels apart
-    epilogue16c<MODE, MT>(p, acc, tile_ok, voff, rbytes, yoff, yrbytes, ec, s4, q4);
+    epilogue16c<MODE, MT, true>(p, acc, tile_ok, voff, rbytes, yoff, yrbytes, ec, s4, q4, ypre);
     if (MODE == MODE_STATS || MODE == MODE_BNBWD) {
       // one partial row per tile (same row count and layout as the other conv kernels); scratch of its own: the stage
       // and patch buffers carry the next item's prefetch.  The >= 9 tap barriers between two tiles order the reuse.
@@ -327,12 +357,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
           else if (t == 4) wait_vmcnt<lat_nsl<PJ, SPT>(2) + BI + lat_nsl<PJ, SPT>(3)>();
           else if (t == 5) wait_vmcnt<lat_nsl<PJ, SPT>(3) + BI + lat_nsl<PJ, SPT>(4)>();
           else if (t == 6) wait_vmcnt<lat_nsl<PJ, SPT>(4) + BI + lat_nsl<PJ, SPT>(5)>();
-          else if (t == 7) wait_vmcnt<lat_nsl<PJ, SPT>(5) + BI + lat_nsl<PJ, SPT>(6)>();
-          else wait_vmcnt<lat_nsl<PJ, SPT>(6) + BI + lat_nsl<PJ, SPT>(7)>();
+          else if (t == 7) { if (NY && last_kc) wait_vmcnt<lat_nsl<PJ, SPT>(5) + BI + lat_nsl<PJ, SPT>(6) + NY>(); else wait_vmcnt<lat_nsl<PJ, SPT>(5) + BI + lat_nsl<PJ, SPT>(6)>(); }
+          else { if (NY && last_kc) wait_vmcnt<lat_nsl<PJ, SPT>(6) + BI + lat_nsl<PJ, SPT>(7) + NY>(); else wait_vmcnt<lat_nsl<PJ, SPT>(6) + BI + lat_nsl<PJ, SPT>(7)>(); }
         } else {
           // single patch buffer: the slices of this chunk were issued after the previous chunk's last tap, behind
           // W(q) and W(q+1) and in front of the epilogue stores
           if (t == 0) { if (boundary) wait_vmcnt<NST>(); else wait_vmcnt<0>(); }
+          else if (t > YT && NY) { if (last_kc) wait_vmcnt<BI + NY>(); else wait_vmcnt<BI>(); }
           else wait_vmcnt<BI>();
         }
         if (!(q.dbg & 1)) raw_barrier();
@@ -344,6 +375,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
 #pragma unroll
           for (int u = 0; u < SPT; ++u)
             if (t * SPT + u < PJ) issue_slice(t * SPT + u, cbuf ^ 1, pb_n, pe_n);
+        }
+        if (MODE == MODE_BNBWD && t == YT && last_kc) {       // after this tap's DMAs: the y fetch is younger than W(q + 2)
+          unsigned voff[MT], yoff[MT];
+          item_offsets(cur, voff, yoff);
+          epi16_prefetch_y<MT>(p, yoff, 2u * (unsigned)d * ldyb, ypre);
         }
         compute_tap(t / 3, t % 3, t % 3, ab);
       }

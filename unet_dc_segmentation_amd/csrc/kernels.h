@@ -50,6 +50,7 @@ struct WgradParams {
 int launch_wgrad(WgradParams& p, float* out, void* workspace, long workspace_bytes, int dtype, hipStream_t stream);
 long wgrad_workspace_bytes(long P, int CI, int CJ, int ntaps, int dtype);
 long wgrad_fused_workspace_bytes(int N, int H, int W, int CI, int CJ, int dtype);
+long wgrad_rect_workspace_bytes(int N, int H, int W, int CI, int CJ, int d);
 
 struct FirstParams {
   const float* x;        // [N][Cin][H][W] fp32

@@ -232,6 +232,11 @@ long wgrad_fused_workspace_bytes(int N, int H, int W, int CI, int CJ, int dtype)
 int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* part, int N, int H, int W, int CI,
                        int CJ, int d, int dtype, int* units_out, hipStream_t stream);
 
+// valid-rectangle kernel for strongly dilated layers, wgrad_rect.hip
+bool wgrad_rect_supported(int N, int H, int W, int CI, int CJ, int lda, int ldb, int d, int ntaps, int stride, int dtype);
+int launch_wgrad_rect(const void* dy, int lddy, const void* x, int ldx, float* out, void* workspace, long workspace_bytes,
+                      int N, int H, int W, int CI, int CJ, int d, hipStream_t stream);
+
 // UNETDC_WGRAD=legacy: first-generation register-staged kernel; =dma: per-tap LDS-DMA kernels only
 // (no tap-fused kernel).  Default: best kernel per layer.
 static int wgrad_choice() {
@@ -324,6 +329,10 @@ int launch_wgrad(WgradParams& p, float* out, void* workspace, long workspace_byt
   const long P = (long)p.N * p.H * p.W;
   UNETDC_REQUIRE(P > 0 && P < (1L << 31) - 4096, "wgrad: pixel count out of range");
   p.P = (int)P;
+  if (wgrad_choice() == 0 && p.Hb == p.H && p.Wb == p.W &&
+      wgrad_rect_supported(p.N, p.H, p.W, p.CI, p.CJ, p.lda, p.ldb, p.offy[8], p.ntaps, p.stride, dtype))
+    return launch_wgrad_rect(p.a, p.lda, p.b, p.ldb, out, workspace, workspace_bytes, p.N, p.H, p.W, p.CI, p.CJ, p.offy[8],
+                             stream);
   if (wgrad_choice() == 0 && p.Hb == p.H && p.Wb == p.W &&
       wgrad_fused_supported(p.N, p.H, p.W, p.CI, p.CJ, p.lda, p.ldb, p.offy[8], p.ntaps, p.stride, dtype)) {
     const long need_f = wgrad_fused_workspace_bytes(p.N, p.H, p.W, p.CI, p.CJ, dtype);

@@ -8,6 +8,7 @@
 #include <stdio.h>
 
 #include "kernels.h"
+#include "lds_dma.h"
 #include "wgrad_frag.h"
 
 namespace unetdc {
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradParams p) 
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lds_base = lds_addr_of(smem);
   const int per_slice = p.ntaps * p.itiles * p.jtiles;
   const int L = xcd_remap(blockIdx.x, gridDim.x);
   const int ks = L / per_slice;
@@ -81,7 +83,6 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradParams p) 
 
   long pcur = pbeg;
   auto issue = [&](int stage) {
-    unsigned char* sbase = smem + stage * STAGE;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const long pp = pcur + rowj[j];
@@ -90,8 +91,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradParams p) 
       const int iy = cy[j] * p.stride + oy, ix = cx[j] * p.stride + ox;
       const bool okb = inr && (unsigned)iy < (unsigned)p.Hb && (unsigned)ix < (unsigned)p.Wb;
       const unsigned vb = okb ? (unsigned)((((long)(cn[j] * p.Hb + iy) * p.Wb + ix) * p.ldb + j0) * ES) + coff[j] : WOOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ar, LDS_PTR(sbase + (wave + NW * j) * 1024), 16, va, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(br, LDS_PTR(sbase + OPB + (wave + NW * j) * 1024), 16, vb, 0, 0, 0);
+      // DMA from inline asm (lds_dma.h): with the builtin, hipcc put an `s_waitcnt vmcnt(0)` in front of the first
+      // transposed fragment read of EVERY step, i.e. the tile just requested for step s+1 had to land before step s
+      // could compute -- no overlap at all (2.5 us per 64-pixel step measured in round 1 = DMA time + MFMA time)
+      lds_dma16(ar, lds_base + stage * STAGE + (wave + NW * j) * 1024, va, 0u);
+      lds_dma16(br, lds_base + stage * STAGE + OPB + (wave + NW * j) * 1024, vb, 0u);
       cx[j] += p.adv_x;
       if (cx[j] >= p.W) { cx[j] -= p.W; ++cy[j]; }
       cy[j] += p.adv_y;
@@ -107,8 +111,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradParams p) 
 
   if (nsteps > 0) issue(0);
   for (int s = 0; s < nsteps; ++s) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    wait_vmcnt<0>();                                   // my pieces of step s have landed ...
+    raw_barrier();                                     // ... everyone's; and everyone has issued the MFMAs of step s-1
     if (s + 1 < nsteps) issue((s + 1) & 1);
     const unsigned char* sa = smem + (s & 1) * STAGE;
     const unsigned char* sb = sa + OPB;

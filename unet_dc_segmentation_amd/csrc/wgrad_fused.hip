@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_fused_kernel(const WgradFusedPar
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lds_base = lds_addr_of(smem);
   const int qi = wave >> 1, qj = wave & 1;
   // block -> (unit, it, jt); unit -> (image, x segment, y range)
   const int L = xcd_remap(blockIdx.x, gridDim.x);
@@ -102,20 +103,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_fused_kernel(const WgradFusedPar
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
   auto issue = [&](int stage, int y) {
-    unsigned char* sbase = smem + stage * STAGE;
 #pragma unroll
     for (int q = 0; q < NSLOT; ++q) {
       const int gi = wave + 4 * q;                                     // wave-uniform
       if (gi < DYI) {
         const unsigned rowbase = (unsigned)((long)(n * p.H + y) * p.W * p.lddy * ES);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(dyr, LDS_PTR(sbase + gi * 1024), 16, rowbase + colb[q], 0, 0, 0);
+        lds_dma16(dyr, lds_base + stage * STAGE + gi * 1024, colb[q], rowbase);
       } else if (gi < DYI + 3 * XI) {
         const int ky = (gi - DYI) / XI, k = (gi - DYI) - ky * XI;
         const int yy = y + (ky - 1) * p.d;
         const bool yok = (unsigned)yy < (unsigned)p.H;
         const unsigned rowbase = (unsigned)((long)(n * p.H + (yok ? yy : 0)) * p.W * p.ldx * ES);
-        const unsigned v = (yok && colb[q] != FOOB) ? rowbase + colb[q] : FOOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, LDS_PTR(sbase + DYB + ky * XB + k * 1024), 16, v, 0, 0, 0);
+        const unsigned v = (yok && colb[q] != FOOB) ? colb[q] : FOOB;
+        lds_dma16(xr, lds_base + stage * STAGE + DYB + ky * XB + k * 1024, v, rowbase);
       }
     }
   };
@@ -123,8 +123,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_fused_kernel(const WgradFusedPar
   const int nsteps = yend - ybeg;
   if (nsteps > 0) issue(0, ybeg);
   for (int s = 0; s < nsteps; ++s) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    wait_vmcnt<0>();                                   // asm DMA + raw barrier: see lds_dma.h
+    raw_barrier();
     if (s + 1 < nsteps) issue((s + 1) & 1, ybeg + s + 1);
     const unsigned char* sdy = smem + (s & 1) * STAGE;
     const unsigned char* sx = sdy + DYB;
