@@ -359,6 +359,223 @@ __global__ __launch_bounds__(256, 2) void wgrad_ring_kernel(const WgradFusedPara
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tap-split ring kernel (bf16): same staging as wgrad_ring_kernel, different split of the work over the four waves.
+//
+// SQ counters of wgrad_ring_kernel (profiles/r02_sq_baseline.json, 128->128 @ 256x256): 2.22 LDS instructions per MFMA,
+// MFMA pipe busy 50 %.  With one 32x32 (co x ci) quadrant and all nine taps per wave, every MFMA needs a B fragment of
+// its own (two ds_read_b64_tr_b16 = 1 KB): 10 fragments per 9 MFMAs.  Four SIMDs x 1 KB per 32-cycle MFMA is more than the
+// LDS delivers, so the matrix pipe waits on fragment reads half the time.
+// Here a wave owns BOTH co halves (64 co x 32 ci) and HALF of the taps: a B fragment feeds two MFMAs.
+//   wave = (qj: ci half, tg: tap group);  tg 0: taps 0..3 and tap 4 on the first two k16 steps of a row,
+//                                         tg 1: taps 5..8 and tap 4 on the last two  (18 B fragments, 36 MFMAs each)
+//   per k16 step: 2 A fragments + 4.5 B fragments for 9 MFMAs  ->  1.44 LDS instructions per MFMA.
+// The two partial sums of tap 4 are added through LDS at the end, tg 0's + tg 1's (fixed order).
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int split_item_k16(int tg, int i) {
+  return tg == 0 ? (i < 10 ? i / 5 : 2 + (i - 10) / 4) : (i < 8 ? i / 4 : 2 + (i - 8) / 5);
+}
+__host__ __device__ constexpr int split_item_tap(int tg, int i) {
+  return tg == 0 ? (i < 10 ? i % 5 : (i - 10) % 4) : (i < 8 ? 5 + i % 4 : 4 + (i - 8) % 5);
+}
+__host__ __device__ constexpr bool split_item_first(int tg, int i) {   // first item of its k16 step
+  return i == 0 || split_item_k16(tg, i) != split_item_k16(tg, i - 1);
+}
+
+template <int TG>
+__device__ __forceinline__ void ring_split_step(f32x16 (&acc)[5][2], const unsigned char* sdy, const unsigned char* sx0,
+                                                const unsigned char* sx1, const unsigned char* sx2, int lane, int qj, int d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NI = 18;
+  bf16x8 fa[2][2], fb[3];
+  auto load_a = [&](int k16) {
+    fa[k16 & 1][0] = Frag<bf16_t, 1>::frag(sdy, lane, 0, 16 * k16);
+    fa[k16 & 1][1] = Frag<bf16_t, 1>::frag(sdy, lane, 32, 16 * k16);
+  };
+  auto load_b = [&](int i) {
+    const int k16 = split_item_k16(TG, i), t = split_item_tap(TG, i), ky = t / 3, kx = t - 3 * ky;
+    const unsigned char* sx = ky == 0 ? sx0 : (ky == 1 ? sx1 : sx2);
+    fb[i % 3] = Frag<bf16_t, 1>::frag(sx, lane, qj * 32, 16 * k16 + kx * d);
+  };
+  load_a(0);
+  load_b(0);
+  load_b(1);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    if (i + 2 < NI) load_b(i + 2);
+    const int k16 = split_item_k16(TG, i);
+    if (split_item_first(TG, i) && k16 + 1 < 4) load_a(k16 + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const int slot = split_item_tap(TG, i) - (TG == 0 ? 0 : 4);
+    acc[slot][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[k16 & 1][0], fb[i % 3], acc[slot][0], 0, 0, 0);
+    acc[slot][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[k16 & 1][1], fb[i % 3], acc[slot][1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#endif
+}
+
+template <int PF, int TG>
+__device__ __forceinline__ void ring_split_body(const WgradFusedParams& p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using T = bf16_t;
+  constexpr int SEG = FusedCfg<T>::SEG;
+  constexpr int XR = SEG + 16;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int RB = 64 * ES;
+  constexpr int CPR = RB / 16, RPI = 64 / CPR;
+  constexpr int DYI = SEG / RPI, XI = XR / RPI;
+  constexpr int GI = DYI + XI;
+  constexpr int NQ = (GI + 3) / 4;
+  constexpr int DYB = SEG * RB, XB = XR * RB;
+  constexpr int NDY = PF + 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const xring = smem + NDY * DYB;
+  const unsigned lds_base = lds_addr_of(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qj = wave & 1;
+  constexpr int tg = TG;
+  const int d = p.d, R = 2 * d + PF + 1;
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles = p.itiles * p.jtiles;
+  const int unit = L / tiles, trem = L - unit * tiles;
+  const int it = trem / p.jtiles, jt = trem - it * p.jtiles;
+  const int i0 = it * 64, j0 = jt * 64;
+  const int segs = p.W / SEG;
+  const int ys = unit % p.ysplit, strip = unit / p.ysplit;
+  const int n = strip / segs, x0 = (strip - n * segs) * SEG;
+  const int ybeg = ys * p.rows_per_unit;
+  const int yend = min(ybeg + p.rows_per_unit, p.H);
+  const int nsteps = yend - ybeg;
+
+  const unsigned dybytes = (unsigned)((long)p.N * p.H * p.W * p.lddy * ES);
+  const unsigned xbytes = (unsigned)((long)p.N * p.H * p.W * p.ldx * ES);
+  const __amdgpu_buffer_rsrc_t dyr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, dybytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, xbytes, 0x00020000);
+
+  const int sub = lane / CPR, pc = lane % CPR;
+  unsigned colb[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int gi = wave + 4 * q;
+    if (gi < DYI) {
+      const int row = gi * RPI + sub;
+      colb[q] = (unsigned)(((x0 + row) * p.lddy + i0) * ES + Frag<T, 1>::src_chunk(row, pc) * 16);
+    } else if (gi < GI) {
+      const int row = (gi - DYI) * RPI + sub;
+      const int gx = x0 - d + row;
+      colb[q] = ((unsigned)gx < (unsigned)p.W) ? (unsigned)((gx * p.ldx + j0) * ES + Frag<T, 1>::src_chunk(row, pc) * 16) : FOOB;
+    } else {
+      colb[q] = FOOB;
+    }
+  }
+  const bool five = (wave + 4 * (NQ - 1)) < GI;
+
+  auto issue_x = [&](int slot, int yy) {
+    const bool yok = (unsigned)yy < (unsigned)p.H;
+    const unsigned rowbase = (unsigned)((long)(n * p.H + (yok ? yy : 0)) * p.W * p.ldx * ES);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int gi = wave + 4 * q;
+      if (gi >= DYI && gi < GI) {
+        const unsigned v = (yok && colb[q] != FOOB) ? colb[q] : FOOB;
+        lds_dma16(xr, lds_base + NDY * DYB + slot * XB + (gi - DYI) * 1024, v, rowbase);
+      }
+    }
+  };
+  auto issue_dy = [&](int slot, int y) {
+    const unsigned rowbase = (unsigned)((long)(n * p.H + y) * p.W * p.lddy * ES);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int gi = wave + 4 * q;
+      if (gi < DYI) lds_dma16(dyr, lds_base + slot * DYB + gi * 1024, colb[q], rowbase);
+    }
+  };
+
+  f32x16 acc[5][2];
+#pragma unroll
+  for (int t = 0; t < 5; ++t)
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][ih][e] = 0.f;
+
+  for (int rho = 0; rho < 2 * d; ++rho) issue_x(rho, ybeg - d + rho);
+  int gslot_x = 2 * d, gslot_dy = 0;
+#pragma unroll
+  for (int k = 0; k < PF; ++k) {
+    if (k < nsteps) {
+      issue_dy(gslot_dy, ybeg + k);
+      issue_x(gslot_x, ybeg + k + d);
+      gslot_dy = (gslot_dy + 1 == NDY) ? 0 : gslot_dy + 1;
+      gslot_x = (gslot_x + 1 == R) ? 0 : gslot_x + 1;
+    }
+  }
+  int sl0 = 0, sl1 = d, sl2 = 2 * d, sdy = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    if (PF == 2 && s + 1 < nsteps) {                     // the group of step s+1 may stay in flight (in-order retirement)
+      if (five) wait_vmcnt<NQ>();
+      else wait_vmcnt<NQ - 1>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    raw_barrier();
+    if (s + PF < nsteps) {
+      issue_dy(gslot_dy, ybeg + s + PF);
+      issue_x(gslot_x, ybeg + s + PF + d);
+      gslot_dy = (gslot_dy + 1 == NDY) ? 0 : gslot_dy + 1;
+      gslot_x = (gslot_x + 1 == R) ? 0 : gslot_x + 1;
+    }
+    const unsigned char* sdyp = smem + sdy * DYB;
+    ring_split_step<TG>(acc, sdyp, xring + sl0 * XB, xring + sl1 * XB, xring + sl2 * XB, lane, qj, d);
+    sl0 = (sl0 + 1 == R) ? 0 : sl0 + 1;
+    sl1 = (sl1 + 1 == R) ? 0 : sl1 + 1;
+    sl2 = (sl2 + 1 == R) ? 0 : sl2 + 1;
+    sdy = (sdy + 1 == NDY) ? 0 : sdy + 1;
+  }
+
+  // ---- tap 4: tg 1's half (slot 0) joins tg 0's (slot 4) through LDS; every DMA has landed (vmcnt(0) on the last step) ----
+  float* xch = reinterpret_cast<float*>(smem);
+  __syncthreads();
+  if (tg == 1) {
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) xch[((qj * 2 + ih) * 16 + reg) * 64 + lane] = acc[0][ih][reg];
+  }
+  __syncthreads();
+  if (tg == 0) {
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) acc[4][ih][reg] += xch[((qj * 2 + ih) * 16 + reg) * 64 + lane];
+  }
+
+  // ---- partial slab: part[unit][t][i][j];  tg 0 stores taps 0..4, tg 1 taps 5..8 ----------------------------------------
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int sl = 0; sl < 5; ++sl) {
+    if (tg == 1 && sl == 0) continue;
+    const int t = sl + (tg == 0 ? 0 : 4);
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih) {
+      float* slab = p.part + ((long)unit * 9 + t) * p.CI * p.CJ + (long)(i0 + ih * 32 + 4 * h) * p.CJ + j0 + qj * 32 + r;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) slab[(long)((reg & 3) + 8 * (reg >> 2)) * p.CJ] = acc[sl][ih][reg];
+    }
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+template <int PF>
+__global__ __launch_bounds__(256, 2) void wgrad_ring_split_kernel(const WgradFusedParams p) {
+  // the tap group is wave-uniform: two specialisations of the whole body, so the 160 accumulator registers of a wave
+  // never meet in a phi (a per-step branch made the allocator spill ~590 registers)
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7) == 0) ring_split_body<PF, 0>(p);
+  else ring_split_body<PF, 1>(p);
+}
+
 // LDS bytes of the ring kernel, or 0 when the configuration does not leave room for two workgroups per CU
 static int ring_lds(int d, int dtype, int pf) {
   const int es = dtype == UNETDC_BF16 ? 2 : 4, seg = dtype == UNETDC_BF16 ? 64 : 32;
@@ -433,6 +650,26 @@ int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* 
   *units_out = units;
   const long nwg = (long)units * p.itiles * p.jtiles;
   const int pf = ring_pf(d, dtype);
+  static int split = -1;                                 // UNETDC_WGRAD_SPLIT=0: quadrant ring kernel (A/B)
+  if (split < 0) { const char* e = getenv("UNETDC_WGRAD_SPLIT"); split = (e && e[0] == '0') ? 0 : 1; }
+  if (pf && dtype == UNETDC_BF16 && split) {
+    const int lds = ring_lds(d, dtype, pf);
+    const void* fn = pf == 2 ? reinterpret_cast<const void*>(&wgrad_ring_split_kernel<2>)
+                             : reinterpret_cast<const void*>(&wgrad_ring_split_kernel<1>);
+    static bool split_attr[3] = {false, false, false};
+    if (!split_attr[pf]) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(wgrad_ring_split_kernel) failed: %s", hipGetErrorString(e));
+        return UNETDC_ELAUNCH;
+      }
+      split_attr[pf] = true;
+    }
+    if (pf == 2) hipLaunchKernelGGL(wgrad_ring_split_kernel<2>, dim3((unsigned)nwg), dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL(wgrad_ring_split_kernel<1>, dim3((unsigned)nwg), dim3(256), lds, stream, p);
+    note_kernel(pf == 2 ? "wgrad_ring_split_kernel<2>" : "wgrad_ring_split_kernel<1>");
+    return check_launch("wgrad_ring_split_kernel");
+  }
   if (pf) {
     const int lds = ring_lds(d, dtype, pf);
     const void* fn;

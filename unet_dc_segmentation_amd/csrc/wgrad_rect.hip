@@ -140,19 +140,22 @@ struct RectReduceParams {
 };
 __global__ __launch_bounds__(256) void wgrad_rect_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                                 const RectReduceParams rp, long n) {
+  // a lane owns four consecutive (co, ci) pairs and all nine taps: float4 reads per slab, 36 consecutive floats written
   const long q = (long)blockIdx.x * 256 + threadIdx.x;     // float4 index into one slab
-  const int t = blockIdx.y;
   if (q * 4 >= n) return;
-  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int u = rp.ufirst[t]; u < rp.ufirst[t + 1]; ++u) {
-    const float4 v = reinterpret_cast<const float4*>(part + (long)u * n)[q];
-    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  float o[36];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = rp.ufirst[t]; u < rp.ufirst[t + 1]; ++u) {
+      const float4 v = reinterpret_cast<const float4*>(part + (long)u * n)[q];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    o[t] = a.x; o[9 + t] = a.y; o[18 + t] = a.z; o[27 + t] = a.w;
   }
-  const long ij = q * 4;
-  out[ij * 9 + t] = a.x;
-  out[(ij + 1) * 9 + t] = a.y;
-  out[(ij + 2) * 9 + t] = a.z;
-  out[(ij + 3) * 9 + t] = a.w;
+  float4* dst = reinterpret_cast<float4*>(out + q * 36);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) dst[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -243,7 +246,7 @@ int launch_wgrad_rect(const void* dy, int lddy, const void* x, int ldx, float* o
     while (tcur < utap[u]) rp.ufirst[++tcur] = u;
   while (tcur < 9) rp.ufirst[++tcur] = nu;
   const long n = (long)CI * CJ;
-  hipLaunchKernelGGL(wgrad_rect_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256), 9), dim3(256), 0, stream, p.part, out, rp, n);
+  hipLaunchKernelGGL(wgrad_rect_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, p.part, out, rp, n);
   return check_launch("wgrad_rect_reduce_kernel");
 }
 
