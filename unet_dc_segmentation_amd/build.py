@@ -45,5 +45,60 @@ def build(force=False, verbose=True):
     return OUT
 
 
+def _objdump():
+    for cand in (shutil.which("llvm-objdump"), "/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("llvm-objdump not found")
+
+
+def device_code_objects(so_path=OUT):
+    """The gfx950 ELF images inside the library: one clang offload bundle per translation unit in .hip_fatbin
+    (header: magic[24], count u64, then per entry offset u64, size u64, id-length u64, id)."""
+    import struct
+    data = open(so_path, "rb").read()
+    magic, pos, out = b"__CLANG_OFFLOAD_BUNDLE__", 0, []
+    while True:
+        i = data.find(magic, pos)
+        if i < 0:
+            return out
+        n, = struct.unpack_from("<Q", data, i + 24)
+        q = i + 32
+        for _ in range(n):
+            off, size, idl = struct.unpack_from("<QQQ", data, q)
+            q += 24
+            tid = data[q:q + idl].decode()
+            q += idl
+            if "gfx950" in tid and size:
+                out.append(data[i + off:i + off + size])
+        pos = i + 24
+
+
+def packed_f32_report(so_path=OUT):
+    """{kernel symbol: number of packed-fp32 VALU instructions (v_pk_add/mul/fma_f32)} over every kernel of the library.
+    The convolution kernels must have none: the packed build of the fused BatchNorm-backward epilogue was not run-to-run
+    deterministic (build() above passes -fno-slp-vectorize; tests/test_entry_points_cpu.py keeps a toolchain or flag
+    change from silently bringing the packed code back)."""
+    import re
+    import tempfile
+    rep = {}
+    for k, elf in enumerate(device_code_objects(so_path)):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(elf)
+            f.flush()
+            r = subprocess.run([_objdump(), "-d", "--no-show-raw-insn", f.name], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("llvm-objdump failed: " + r.stderr[:300])
+        cur = None
+        for line in r.stdout.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                cur = m.group(1)
+                rep.setdefault(cur, 0)
+            elif cur and re.search(r"\bv_pk_(add|mul|fma)_f32\b", line):
+                rep[cur] += 1
+    return rep
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
