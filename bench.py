@@ -251,6 +251,9 @@ def hbm_bytes(name, a, es):
     if name == "unetdc_head_bwd":                          # dprobs, probs, a -> da
         n, h, w, c, oc = a[11:16]
         return n * h * w * (2 * c * es + 2 * oc * 4)
+    if name == "unetdc_head_bwd_bnstats":                  # dprobs, probs, a, y (of the last stage) -> da
+        n, h, w, c, oc = a[20:25]
+        return n * h * w * (3 * c * es + 2 * oc * 4)
     if name == "unetdc_conv3x3_first_fwd":                 # x (fp32 NCHW) -> y
         n, h, w, cin, cout = a[8:13]
         return n * h * w * (cin * 4 + cout * es)
@@ -260,7 +263,7 @@ def hbm_bytes(name, a, es):
     raise KeyError(name)
 
 
-HBM_CALLS = ["unetdc_bn_relu_apply", "unetdc_bn_relu_bwd", "unetdc_head_fwd", "unetdc_head_bwd",
+HBM_CALLS = ["unetdc_bn_relu_apply", "unetdc_bn_relu_bwd", "unetdc_head_fwd", "unetdc_head_bwd", "unetdc_head_bwd_bnstats",
              "unetdc_conv3x3_first_fwd", "unetdc_conv3x3_first_wgrad"]
 
 

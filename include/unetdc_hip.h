@@ -184,6 +184,15 @@ int64_t unetdc_head_bwd_workspace(int n, int h, int w, int c, int oc, int dtype)
 int unetdc_head_bwd(const float* dprobs, const float* probs, const void* a, int lda, const float* w, void* da,
                     int ldda, float* dw, float* db, void* workspace, int64_t workspace_bytes, int n, int h, int wd,
                     int c, int oc, int dtype, unetdc_stream_t s);
+/* head_bwd that also produces the BatchNorm-backward partial sums of the stage whose activated output `a` is (the
+ * block feeding out_conv, models/model_2.py:76-79), in the layout unetdc_bn_relu_bwd takes as pre_parts: the
+ * gradient da is then read once by that stage's backward instead of twice.  y_prev/scale/shift/mean/rstd: that
+ * stage's saved conv output and batch statistics; parts needs (rows + 64) * 3 * c floats, *nparts receives rows. */
+int unetdc_head_bwd_bnstats(const float* dprobs, const float* probs, const void* a, int lda, const float* w, void* da,
+                            int ldda, float* dw, float* db, void* workspace, int64_t workspace_bytes, const void* y_prev,
+                            int ldy_prev, const float* scale, const float* shift, const float* mean, const float* rstd,
+                            float* parts, int64_t parts_floats, int* nparts, int n, int h, int wd, int c, int oc, int dtype,
+                            unetdc_stream_t s);
 
 /* ---- fused Focal + Dice loss on probabilities: utils/metrics_DC.py:65-73 (FocalLoss :43-63, dice_loss :11-17) ---
  * probs/target: fp32 [nimg][hw] (nimg = N*C maps, hw pixels each).  fwd writes the scalar loss and the

@@ -321,6 +321,61 @@ def test_head_fwd_bwd(dtype, oc):
     assert rel(G.from_nhwc(dav, n, h, w), ga_ref) < (1e-5 if dtype == "f32" else (4e-3 if oc == 1 else 8e-3))
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 16, 24, 1), (1, 64, 64, 1), (3, 160, 96, 2)])
+def test_head_bwd_fused_bn_backward_sums(dtype, shape):
+    """unetdc_head_bwd_bnstats: same da (bitwise) / dw / db as unetdc_head_bwd, and partial rows whose column sums are the
+    BatchNorm-backward sums S1 = sum dyhat, S2 = sum dyhat * xhat, S3 = sum xhat of the stored gradient (fp64 restatement
+    of csrc/elementwise.hip bn_bwd_kernel on the device's own da and y)."""
+    import ctypes
+    n, h, w, oc = shape
+    c = 64
+    g = gen(29)
+    y = G.quant(torch.randn(n, c, h, w, generator=g), dtype)
+    scale, shift = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    mean, rstd = torch.randn(c, generator=g) * 0.2, torch.rand(c, generator=g) + 0.5
+    a = G.quant(torch.relu(y * scale.view(1, c, 1, 1) + shift.view(1, c, 1, 1)), dtype)
+    wt = torch.randn(oc, c, generator=g) * 0.3
+    probs = torch.rand(n, oc, h, w, generator=g).cuda()
+    dp = torch.randn(n, oc, h, w, generator=g).cuda()
+    av, yv = G.to_nhwc(a, dtype), G.to_nhwc(y, dtype)
+    wd2 = wt.cuda().contiguous()
+    nbytes = _lib.load().unetdc_head_bwd_workspace(n, h, w, c, oc, G.DT[dtype])
+    ws = G.workspace(nbytes)
+    outs = []
+    rows = _lib.load().unetdc_conv3x3_stats_rows(n * h * w, c)
+    parts = torch.full(((rows + 64) * 3 * c,), float("nan"), device="cuda")
+    dv = [t.cuda() for t in (scale, shift, mean, rstd)]
+    npar = ctypes.c_int(0)
+    for fused in (False, True):
+        dav = G.empty_nhwc(n * h * w, c, dtype)
+        dw, db = torch.full((oc, c), float("nan"), device="cuda"), torch.full((oc,), float("nan"), device="cuda")
+        if fused:
+            call("unetdc_head_bwd_bnstats", dp.data_ptr(), probs.data_ptr(), av.data_ptr(), av.stride(0), wd2.data_ptr(),
+                 dav.data_ptr(), dav.stride(0), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nbytes, yv.data_ptr(),
+                 yv.stride(0), dv[0].data_ptr(), dv[1].data_ptr(), dv[2].data_ptr(), dv[3].data_ptr(), parts.data_ptr(),
+                 parts.numel(), ctypes.byref(npar), n, h, w, c, oc, G.DT[dtype], G.stream())
+        else:
+            call("unetdc_head_bwd", dp.data_ptr(), probs.data_ptr(), av.data_ptr(), av.stride(0), wd2.data_ptr(),
+                 dav.data_ptr(), dav.stride(0), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nbytes, n, h, w, c, oc,
+                 G.DT[dtype], G.stream())
+        torch.cuda.synchronize()
+        outs.append((dav.clone(), dw.clone(), db.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])               # da: bitwise
+    for u, v in zip(outs[0][1:], outs[1][1:]):               # dw, db: the fused launch may take fewer workgroups (rows of `parts`)
+        assert rel(u.cpu(), v.cpu()) < 1e-5
+    assert 1 <= npar.value <= rows + 64
+    got = parts[: npar.value * 3 * c].view(npar.value, 3, c).double().sum(0).cpu()
+    da = outs[1][0].double().cpu()[:, :c]                      # [pixels][c], as stored
+    yy = yv.double().cpu()[:, :c]
+    gate = (yy * scale.double() + shift.double()) > 0           # sign of the exact value = sign of the kernel's fp32 fma
+    gh = torch.where(gate, da, torch.zeros_like(da))
+    xh = (yy - mean.double()) * rstd.double()
+    ref = torch.stack([gh.sum(0), (gh * xh).sum(0), xh.sum(0)])
+    tol = 2e-5 * (ref.abs().max() + (gh.abs().sum(0).max()))
+    assert float((got - ref).abs().max()) < float(tol), float((got - ref).abs().max())
+
+
 def test_argument_errors_are_reported():
     """Error behaviour of the boundary: bad shapes return a negative code + message, no crash."""
     x = torch.zeros(64, 48, device="cuda")

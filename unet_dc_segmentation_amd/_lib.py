@@ -51,6 +51,7 @@ SIGNATURES = {
     "unetdc_head_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, P]),
     "unetdc_head_bwd_workspace": (L, [I, I, I, I, I, I]),
     "unetdc_head_bwd": (I, [P, P, P, I, P, P, I, P, P, P, L, I, I, I, I, I, I, P]),
+    "unetdc_head_bwd_bnstats": (I, [P, P, P, I, P, P, I, P, P, P, L, P, I, P, P, P, P, P, L, P, I, I, I, I, I, I, P]),
     "unetdc_focal_dice_loss_workspace": (L, [I, L]),
     "unetdc_focal_dice_loss_fwd": (I, [P, P, P, P, P, L, I, L, F, F, F, F, P]),
     "unetdc_focal_dice_loss_bwd": (I, [P, P, P, P, P, I, L, F, F, F, P]),

@@ -334,6 +334,21 @@ int unetdc_head_bwd(const float* dprobs, const float* probs, const void* a, int 
   return launch_head_bwd(p, dw, db, workspace, (long)workspace_bytes, dtype, (hipStream_t)s);
 }
 
+int unetdc_head_bwd_bnstats(const float* dprobs, const float* probs, const void* a, int lda, const float* w, void* da,
+                            int ldda, float* dw, float* db, void* workspace, int64_t workspace_bytes, const void* y_prev,
+                            int ldy_prev, const float* scale, const float* shift, const float* mean, const float* rstd,
+                            float* parts, int64_t parts_floats, int* nparts, int n, int h, int wd, int c, int oc, int dtype,
+                            unetdc_stream_t s) {
+  GEOM_CHECK(n, h, wd);
+  UNETDC_REQUIRE(y_prev && scale && shift && mean && rstd && parts && nparts, "head_bwd_bnstats: null pointer");
+  HeadParams p{};
+  p.a = a; p.w = w; p.probs = const_cast<float*>(probs); p.dprobs = dprobs; p.da = da;
+  p.N = n; p.H = h; p.W = wd; p.C = c; p.OC = oc; p.lda = lda; p.ldda = ldda;
+  p.bn_y = y_prev; p.bn_ldy = ldy_prev; p.bn_scale = scale; p.bn_shift = shift; p.bn_mean = mean; p.bn_rstd = rstd;
+  p.bn_parts = parts;
+  return launch_head_bwd(p, dw, db, workspace, (long)workspace_bytes, dtype, (hipStream_t)s, nparts, (long)parts_floats);
+}
+
 int64_t unetdc_focal_dice_loss_workspace(int nimg, int64_t hw) { return loss_workspace_bytes(nimg, (long)hw); }
 
 int unetdc_focal_dice_loss_fwd(const float* probs, const float* target, float* loss_out, float* coef, void* workspace,

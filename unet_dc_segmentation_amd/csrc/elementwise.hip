@@ -339,16 +339,31 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadParams p) {
 
 // dz = dp * p * (1-p);  dA[pix][c] = sum_oc dz[oc]*w[oc][c];  partial sums of dz*a (dW) and dz (db)
 // parts layout: [gridDim.x][OC][C + 1]   (last column = bias gradient)
-template <typename T>
+template <typename T, bool BN>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadParams p) {
   constexpr int EPC = Chunk<T>::N;
   __shared__ float red[256 * (EPC + 1)];
+  __shared__ float red3[BN ? 256 * 3 * EPC : 1];
   const int cpp = p.C / EPC, ppb = 256 / cpp;
   const int tid = threadIdx.x, cl = tid % cpp, pl = tid / cpp;
   const long HW = (long)p.H * p.W, P = (long)p.N * HW;
   const T* __restrict__ ag = reinterpret_cast<const T*>(p.a);
   T* __restrict__ dag = reinterpret_cast<T*>(p.da);
+  // BN: the gradient written here is the activation gradient of the stage that produced `a`; its BatchNorm-backward
+  // sums (S1 = sum dyhat, S2 = sum dyhat*xhat, S3 = sum xhat: see bn_bwd_kernel) are taken from the value as STORED
+  // (rounded through the storage type), so the stand-alone reduction pass over da and y is not needed.
+  const T* __restrict__ yg = reinterpret_cast<const T*>(p.bn_y);
+  float sc[EPC], sh[EPC], mu[EPC], rs[EPC], s1[EPC], s2[EPC], s3[EPC];
+  if (BN) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const int c = cl * EPC + e;
+      sc[e] = p.bn_scale[c]; sh[e] = p.bn_shift[c]; mu[e] = p.bn_mean[c]; rs[e] = p.bn_rstd[c];
+      s1[e] = s2[e] = s3[e] = 0.f;
+    }
+  }
   for (int oc = 0; oc < p.OC; ++oc) {
+    const bool last = oc == p.OC - 1;
     float wv[EPC], gw[EPC], gb = 0.f;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { wv[e] = p.w[oc * p.C + cl * EPC + e]; gw[e] = 0.f; }
@@ -359,8 +374,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadParams p) {
       const long o = (n * p.OC + oc) * HW + rem;
       const float pr = p.probs[o];
       const float dz = p.dprobs[o] * pr * (1.f - pr);
-      float av[EPC], d[EPC];
+      float av[EPC], d[EPC], yv[EPC];
       Chunk<T>::unpack(ld16(ag + pix * p.lda + cl * EPC), av);
+      if (BN && last) Chunk<T>::unpack(ld16(yg + pix * p.bn_ldy + cl * EPC), yv);
       if (oc > 0) Chunk<T>::unpack(ld16(dag + pix * p.ldda + cl * EPC), d);
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
@@ -369,6 +385,16 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadParams p) {
       }
       if (cl == 0) gb += dz;
       st16(dag + pix * p.ldda + cl * EPC, Chunk<T>::pack(d));
+      if (BN && last) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const float g = round_through<T>(d[e]);
+          const float nrm = fmaf(yv[e], sc[e], sh[e]);
+          const float gh = nrm > 0.f ? g : 0.f;
+          const float xh = (yv[e] - mu[e]) * rs[e];
+          s1[e] += gh; s2[e] = fmaf(gh, xh, s2[e]); s3[e] += xh;
+        }
+      }
     }
 #pragma unroll
     for (int e = 0; e < EPC; ++e) red[tid * (EPC + 1) + e] = gw[e];
@@ -385,6 +411,21 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadParams p) {
       p.parts[((long)blockIdx.x * p.OC + oc) * (p.C + 1) + i] = s;
     }
     __syncthreads();
+  }
+  if (BN) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      red3[(tid * 3 + 0) * EPC + e] = s1[e];
+      red3[(tid * 3 + 1) * EPC + e] = s2[e];
+      red3[(tid * 3 + 2) * EPC + e] = s3[e];
+    }
+    __syncthreads();
+    for (int i = tid; i < 3 * p.C; i += 256) {             // (which, channel): pixel lanes summed in lane order
+      const int which = i / p.C, c = i - which * p.C, c2 = c / EPC, e = c - c2 * EPC;
+      float s = 0.f;
+      for (int q = 0; q < ppb; ++q) s += red3[((q * cpp + c2) * 3 + which) * EPC + e];
+      p.bn_parts[((long)blockIdx.x * 3 + which) * p.C + c] = s;
+    }
   }
 }
 
@@ -730,21 +771,38 @@ int launch_head_fwd(HeadParams& p, int dtype, hipStream_t stream) {
 }
 
 int launch_head_bwd(HeadParams& p, float* dw, float* db, void* workspace, long workspace_bytes, int dtype,
-                    hipStream_t stream) {
+                    hipStream_t stream, int* bn_nparts, long bn_parts_floats) {
   int rc = check_head(p, dtype);
   if (rc != UNETDC_OK) return rc;
   UNETDC_REQUIRE(p.dprobs && p.da && dw && db && workspace, "head_bwd: null pointer");
   const int epc = dtype == UNETDC_BF16 ? 8 : 4;
   UNETDC_REQUIRE(p.ldda % epc == 0, "head_bwd: ldda not chunk aligned");
-  const int nb = head_blocks((long)p.N * p.H * p.W, p.C / epc);
+  int nb = head_blocks((long)p.N * p.H * p.W, p.C / epc);
+  const bool bn = p.bn_y != nullptr;
+  if (bn) {
+    UNETDC_REQUIRE(p.bn_scale && p.bn_shift && p.bn_mean && p.bn_rstd && p.bn_parts && bn_nparts,
+                   "head_bwd_bnstats: null pointer");
+    UNETDC_REQUIRE(p.bn_ldy % epc == 0 && p.bn_ldy >= p.C, "head_bwd_bnstats: ldy not chunk aligned");
+    // the caller sized `parts` for a convolution epilogue (one row per 256 pixels + 64 spare rows): the grid-stride loop
+    // of this kernel takes as many workgroups as that buffer has rows for
+    const long cap = bn_parts_floats / (3L * p.C) - 64;
+    if (nb > cap) nb = (int)cap;
+    UNETDC_REQUIRE(nb >= 1, "head_bwd_bnstats: partial buffer too small");
+    *bn_nparts = nb;
+  }
   const long need = ((long)nb + 64) * p.OC * (p.C + 1) * 4;
   if (need > workspace_bytes) {
     set_error("head_bwd: workspace too small (%ld < %ld bytes)", workspace_bytes, need);
     return UNETDC_EWORKSPACE;
   }
   p.parts = reinterpret_cast<float*>(workspace);
-  if (dtype == UNETDC_BF16) hipLaunchKernelGGL(head_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL(head_bwd_kernel<float>, dim3(nb), dim3(256), 0, stream, p);
+  if (dtype == UNETDC_BF16) {
+    if (bn) hipLaunchKernelGGL((head_bwd_kernel<bf16_t, true>), dim3(nb), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((head_bwd_kernel<bf16_t, false>), dim3(nb), dim3(256), 0, stream, p);
+  } else {
+    if (bn) hipLaunchKernelGGL((head_bwd_kernel<float, true>), dim3(nb), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((head_bwd_kernel<float, false>), dim3(nb), dim3(256), 0, stream, p);
+  }
   rc = check_launch("head_bwd_kernel");
   if (rc != UNETDC_OK) return rc;
   const int L = p.OC * (p.C + 1);

@@ -95,6 +95,10 @@ struct HeadParams {
   const void* a; const float* w; const float* b; float* probs;
   const float* dprobs; void* da; float* parts;      // backward
   int N, H, W, C, OC, lda, ldda;
+  // optional: BatchNorm-backward partial sums of the stage that produced `a` (its saved conv output y + batch statistics)
+  const void* bn_y; const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_rstd;
+  float* bn_parts;  // [gridDim.x][3][C]
+  int bn_ldy;
 };
 int launch_bn_finalize(const float* parts, int nparts, long count, const float* gamma, const float* beta, float eps,
                        float momentum, float* rm, float* rv, float* scale, float* shift, float* mean, float* rstd,
@@ -110,7 +114,7 @@ int launch_bn_bwd_reduce_only(BnBwdParams& p, float* parts, long parts_floats, i
 long head_bwd_workspace_bytes(int N, int H, int W, int C, int OC, int dtype);
 int launch_head_fwd(HeadParams& p, int dtype, hipStream_t stream);
 int launch_head_bwd(HeadParams& p, float* dw, float* db, void* workspace, long workspace_bytes, int dtype,
-                    hipStream_t stream);
+                    hipStream_t stream, int* bn_nparts = nullptr, long bn_parts_floats = 0);
 int launch_pack_conv3x3(const float* w, void* wf, void* wd, int Co, int Ci, int dtype, hipStream_t stream);
 int launch_pack_convT2x2(const float* w, void* wf, void* wd, int Ci, int Co, int dtype, hipStream_t stream);
 int launch_pack_many(const void* table_dev, int n, long total, int dtype, hipStream_t stream);

@@ -461,10 +461,18 @@ class UNetEngine:
         dprobs = dprobs.contiguous()
         oc = self.model.out_conv
         da = g[("da", 0)]
-        call("unetdc_head_bwd", dprobs.data_ptr(), probs.data_ptr(), self.head_in.data_ptr(),
-             self.head_in.stride(0), oc.weight.data_ptr(), da.data_ptr(), da.stride(0),
-             self._gview(flat, oc.weight).data_ptr(), self._gview(flat, oc.bias).data_ptr(), ws, wsb,
-             N, self.H, self.W, 64, self.oc, self.dt, s)
+        last = self.stages[("dec1", 3)]                  # its activated output feeds out_conv
+        if FUSE_BN_BWD:                                  # da's BatchNorm-backward sums come out of the same pass
+            call("unetdc_head_bwd_bnstats", dprobs.data_ptr(), probs.data_ptr(), self.head_in.data_ptr(),
+                 self.head_in.stride(0), oc.weight.data_ptr(), da.data_ptr(), da.stride(0),
+                 self._gview(flat, oc.weight).data_ptr(), self._gview(flat, oc.bias).data_ptr(), ws, wsb,
+                 *self._bnstats_args(last), N, self.H, self.W, 64, self.oc, self.dt, s)
+            last.bwd_nparts = self._np.value
+        else:
+            call("unetdc_head_bwd", dprobs.data_ptr(), probs.data_ptr(), self.head_in.data_ptr(),
+                 self.head_in.stride(0), oc.weight.data_ptr(), da.data_ptr(), da.stride(0),
+                 self._gview(flat, oc.weight).data_ptr(), self._gview(flat, oc.bias).data_ptr(), ws, wsb,
+                 N, self.H, self.W, 64, self.oc, self.dt, s)
         self._notify(flat, "out_conv")
         # decoder, level 1 (full resolution) up to level 4
         dact = da                               # gradient of the current block's activated output
