@@ -345,6 +345,13 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))
 
+    # The contract is ONE JSON line on stdout.  RCCL prints a five-line version banner on stdout when its first
+    # communicator comes up (seen on the MI355X box with torch's bundled librccl), so file descriptor 1 is pointed at
+    # stderr for the whole run and the JSON line goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     from unet_dc_segmentation_amd import _lib, dp as dpmod
     from utils.metrics_DC import focal_dice_loss
     # RCCL ("nccl") is the production backend; UNETDC_DIST_BACKEND=gloo + UNETDC_BENCH_DEVICE=0 lets several
@@ -367,7 +374,9 @@ def main():
     torch.manual_seed(0)                                   # identical replicas
     model = Net(in_channels=args.in_channels, out_channels=1).to(dev).train()
     model.set_compute_dtype(args.dtype)
-    wrapper = dpmod.DataParallel(model) if world > 1 else None
+    # UNETDC_DP_FORCE=1: a one-rank process group whose collectives are really issued (RCCL rehearsal on a one-GPU box)
+    force_dp = os.environ.get("UNETDC_DP_FORCE") == "1"
+    wrapper = dpmod.DataParallel(model, single_rank_collectives=force_dp) if (world > 1 or force_dp) else None
     # train_DC_focal.py:224 (Adam, lr 1e-3): the same update rule in ONE HIP kernel that also rewrites the packed weight
     # images (unet_dc_segmentation_amd/optim.py); --adam fused / foreach select torch.optim.Adam for comparison
     if args.adam == "hip":
@@ -482,8 +491,8 @@ def main():
                                  "payload_MB_per_step": wrapper.stats["elems"] * 4 / max(wrapper.stats["steps"], 1) / 1e6}
         if world == 1 and not args.no_cpu_baseline and args.mode == "train":
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.size, args.size, args.in_channels)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

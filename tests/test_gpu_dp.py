@@ -95,3 +95,54 @@ def test_hip_backward_with_bucketed_allreduce_two_ranks_one_gpu():
         p.join(60)
     assert all(r[1] == "ok" for r in results), results
     print("DP rehearsal:", results)
+
+
+def _rccl_worker(port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+                          HSA_ENABLE_IPC_MODE_LEGACY="0")
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1)          # "nccl" IS RCCL on ROCm
+        from models.model_2 import UNetDC
+        from oracle import recipe
+        from unet_dc_segmentation_amd.dp import DataParallel
+        from utils.metrics_DC import focal_dice_loss
+        torch.manual_seed(7)
+        model = UNetDC(1, 1).cuda().train()
+        model.set_compute_dtype("bf16")
+        x = recipe.seeded_input(50, (2, 1, 128, 128)).cuda()
+        t = recipe.seeded_target(60, (2, 1, 128, 128)).cuda()
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        focal_dice_loss(model(x), t).backward()                          # no exchange
+        torch.cuda.synchronize()
+        ref = [p.grad.clone() for p in model.parameters()]
+        model.load_state_dict(sd0)
+        dp = DataParallel(model, bucket_bytes=16 << 20, single_rank_collectives=True)
+        model.zero_grad(set_to_none=True)
+        focal_dice_loss(model(x), t).backward()                          # every bucket goes through ncclAllReduce(AVG)
+        torch.cuda.synchronize()
+        for p, g in zip(model.parameters(), ref):
+            assert torch.equal(p.grad, g)                                # AVG over one rank is the identity, bit for bit
+        assert dp.stats["buckets"] >= 2 and dp.stats["elems"] == sum(p.numel() for p in model.parameters())
+        dp.broadcast_buffers()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put(("ok", dp.stats["buckets"]))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put(("FAIL: " + repr(e) + "\n" + traceback.format_exc(), 0))
+
+
+@pytest.mark.timeout(600)
+def test_rccl_branch_executes_on_one_rank():
+    """The RCCL ('nccl') branch of dp.py -- async all_reduce(AVG) on slices of the flat gradient buffer behind the HIP
+    backward, finish() on the compute stream -- run for real on the one card a test box has (one-rank group with
+    single_rank_collectives=True).  The N > 1 arithmetic is covered by the gloo tests; this covers the backend calls."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=500)
+    p.join(60)
+    assert res[0] == "ok", res

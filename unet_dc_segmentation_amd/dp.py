@@ -28,12 +28,15 @@ import torch.distributed as dist
 
 
 class DataParallel:
-    def __init__(self, model, process_group=None, bucket_bytes=16 << 20, broadcast=True):
+    def __init__(self, model, process_group=None, bucket_bytes=16 << 20, broadcast=True, single_rank_collectives=False):
+        """``single_rank_collectives``: issue the collectives even in a one-rank group (RCCL then runs every call of the
+        exchange on one card: the rehearsal of the multi-GPU path that a one-GPU box allows, tests/test_gpu_dp.py)."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed must be initialised (backend 'nccl' = RCCL on ROCm, or 'gloo')")
         self.model = model
         self.pg = process_group
         self.world = dist.get_world_size(process_group)
+        self.active = self.world > 1 or single_rank_collectives
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.backend = dist.get_backend(process_group)
         self._works = []
@@ -74,7 +77,7 @@ class DataParallel:
 
     def _on_ready(self, flat, lo, hi):
         """Called by the backward schedule: gradients flat[lo:hi] are enqueued on the compute stream."""
-        if self.world == 1:
+        if not self.active:
             return
         if self._pending is not None and self._pending[0] is flat and self._pending[1] == hi:
             lo, hi = lo, self._pending[2]                   # extend the pending range downwards
@@ -102,7 +105,7 @@ class DataParallel:
         """All-reduce ``param.grad`` of every parameter (used when backward did not go through the
         HIP engine, i.e. CPU tensors with the gloo backend)."""
         params = [p for p in self.model.parameters() if p.grad is not None]
-        if self.world == 1 or not params:
+        if not self.active or not params:
             return
         flat = torch.cat([p.grad.reshape(-1) for p in params])
         n = flat.numel()
@@ -135,7 +138,7 @@ def init_from_env(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("UNETDC_DP_FORCE") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
