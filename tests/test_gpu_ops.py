@@ -145,9 +145,10 @@ def test_wgrad_many_pixels_ksplit(dtype):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("cin", [1, 3])
-@pytest.mark.parametrize("shape", [(2, 24, 40, 1), (2, 64, 64, 2), (3, 10, 10, 1)])
+@pytest.mark.parametrize("shape", [(2, 24, 40, 1), (2, 64, 64, 2), (3, 10, 10, 1), (1, 8, 8, 1), (2, 96, 136, 1)])
 def test_first_conv(dtype, cin, shape):
-    """(2,24,40): fp32-MFMA kernels, division path; (2,64,64) d=2: shift path, several workgroups;
+    """(2,24,40): fp32-MFMA kernels, division path; (2,64,64) d=2: shift path, several workgroups; W % 8 == 0 with d = 1 and
+    C_in = 1: the row-run weight-gradient kernel (one run per row at 8 x 8: both edges in one run; 96 x 136: several trips);
     (3,10,10): pixel count not a multiple of 32 -> VALU kernels of first_conv.hip."""
     n, h, w, d = shape
     cout = 64

@@ -9,6 +9,9 @@
 //   * BatchNorm batch statistics (sum, sum of squares of the stored values) are reduced per block.
 // The matching weight gradient streams dY once per input channel and keeps the 9 x 8 products per
 // lane in registers; block partials are summed by a second deterministic kernel.
+#include <stdint.h>
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace unetdc {
@@ -157,6 +160,86 @@ __global__ __launch_bounds__(256) void first_conv_wgrad_kernel(const FirstWgradP
   }
 }
 
+// Row-run form (dilation 1, W % 8 == 0: the first layer of both networks).  SQ/TA view of the kernel above: 9 bounds-checked
+// 4-byte input loads and ~50 address instructions per 16 bytes of dY, 512 workgroups -> 1.5 TB/s on a pass whose only real
+// traffic is dY.  Here a lane owns 8 channels and walks RUNS of 8 consecutive pixels of one image row: the 3 x 10 input window
+// of a run is loaded once (two float4 + two edge values per row: 12 loads per 8 pixels instead of 72) and slides through
+// registers; the eight dY chunks of a run are issued together.
+template <typename T>
+__global__ __launch_bounds__(256) void first_wgrad_rows_kernel(const FirstWgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) float red[];    // [4 waves][G][72]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = p.Cout / 8, PPB = 256 / G;
+  const int g = tid % G, pl = tid / G;
+  const int ci = blockIdx.y;
+  const int HW = p.H * p.W, rpr = p.W / 8;
+  const long runs = (long)p.N * p.H * rpr;
+  const T* __restrict__ dyg = reinterpret_cast<const T*>(p.dy);
+  float acc[9][8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+
+  for (long r = (long)blockIdx.x * PPB + pl; r < runs; r += (long)gridDim.x * PPB) {
+    const int n = (int)(r / ((long)p.H * rpr));
+    const int rem = (int)(r - (long)n * p.H * rpr);
+    const int y = rem / rpr, x0 = (rem - y * rpr) * 8;
+    const float* xp = p.x + (long)(n * p.Cin + ci) * HW;
+    float xw[3][10];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = y + ky - 1;
+      const bool ok = (unsigned)iy < (unsigned)p.H;
+      const float* row = xp + (long)(ok ? iy : y) * p.W + x0;
+      const float4 a = *reinterpret_cast<const float4*>(row), b = *reinterpret_cast<const float4*>(row + 4);
+      const float l = x0 > 0 ? row[-1] : 0.f, rr = x0 + 8 < p.W ? row[8] : 0.f;
+      const float m = ok ? 1.f : 0.f;                        // rows outside the image contribute zeros
+      xw[ky][0] = l * m; xw[ky][1] = a.x * m; xw[ky][2] = a.y * m; xw[ky][3] = a.z * m; xw[ky][4] = a.w * m;
+      xw[ky][5] = b.x * m; xw[ky][6] = b.y * m; xw[ky][7] = b.z * m; xw[ky][8] = b.w * m; xw[ky][9] = rr * m;
+    }
+    const long pix0 = ((long)n * p.H + y) * p.W + x0;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {                       // four pixels' chunks in flight at a time (register budget)
+      float d[4][8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 8 / Chunk<T>::N; ++q)
+          Chunk<T>::unpack(ld16(dyg + (pix0 + 4 * hf + i) * p.lddy + g * 8 + q * Chunk<T>::N), d[i] + q * Chunk<T>::N);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const float xv = xw[t / 3][4 * hf + i + t % 3];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[t][e] = fmaf(xv, d[i][e], acc[t][e]);
+        }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = acc[t][e];
+      for (int o = G; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+      acc[t][e] = v;
+    }
+  if (lane < G) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[(wave * G + lane) * 72 + t * 8 + e] = acc[t][e];
+  }
+  __syncthreads();
+  for (int i = tid; i < 9 * p.Cout; i += 256) {
+    const int t = i / p.Cout, co = i - t * p.Cout, gg = co / 8, e = co % 8;
+    float s = 0.f;
+    for (int w2 = 0; w2 < 4; ++w2) s += red[(w2 * G + gg) * 72 + t * 8 + e];
+    p.part[(((long)blockIdx.x * p.Cin + ci) * 9 + t) * p.Cout + co] = s;
+  }
+}
+
 // dw[co][ci][t] = sum_blk part[blk][ci][t][co]
 // 32 lanes per output: lane l adds blocks l, l+32, ... in order, then a fixed shuffle tree (deterministic).  One thread
 // per output walking all 512 block partials took 120 us -- pure load latency on three workgroups.
@@ -208,11 +291,19 @@ int launch_first_fwd(FirstParams& p, int dtype, hipStream_t stream) {
 // channel but is as fast for Cin = 1 (measured 155 vs 169 us at 8 x 512 x 512), so the MFMA kernel serves Cin = 3.
 static bool first_wgrad_mfma(long P, int Cin, int Cout) { return Cin > 1 && first_mfma_supported(P, Cin, Cout); }
 
+constexpr long FIRST_ROWS_MAXB = 512;     // measured at 8 x 512 x 512: 2048 -> 122 us, 1024 -> 106, 512 -> 79, 256 -> 98
+static long first_rows_blocks(long P, int Cout) {          // row-run kernel: one run of 8 pixels per lane group and trip
+  const long ppb = 256 / (Cout / 8);
+  long nb = (P / 8 + ppb - 1) / ppb;
+  return nb > FIRST_ROWS_MAXB ? FIRST_ROWS_MAXB : (nb < 1 ? 1 : nb);
+}
+
 long first_wgrad_workspace_bytes(long P, int Cin, int Cout) {
   if (first_wgrad_mfma(P, Cin, Cout)) return first_mfma_wgrad_workspace_bytes(P, Cin, Cout);
   long nb = first_blocks(P, Cout);
   if (nb > 512) nb = 512;
-  return nb * Cin * 9 * Cout * 4;
+  const long nr = first_rows_blocks(P, Cout);            // whichever VALU kernel the launch picks (dilation / W decide there)
+  return (nb > nr ? nb : nr) * Cin * 9 * Cout * 4;
 }
 
 int launch_first_wgrad(FirstWgradParams& p, float* dw, void* workspace, long workspace_bytes, int dtype,
@@ -240,6 +331,23 @@ int launch_first_wgrad(FirstWgradParams& p, float* dw, void* workspace, long wor
     return check_launch("first_wgrad_reduce_kernel");
   }
   const size_t lds = (size_t)4 * (p.Cout / 8) * 72 * 4;
+  static int rows_off = -1;                              // UNETDC_FIRST_ROWS=0: the per-pixel kernel (A/B)
+  if (rows_off < 0) { const char* e = getenv("UNETDC_FIRST_ROWS"); rows_off = (e && e[0] == '0') ? 1 : 0; }
+  if (!rows_off && p.dil == 1 && p.W % 8 == 0 && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0) {
+    const long nr = first_rows_blocks(P, p.Cout);
+    if (nr * p.Cin * 9 * p.Cout * 4 <= workspace_bytes) {
+      if (dtype == UNETDC_BF16)
+        hipLaunchKernelGGL(first_wgrad_rows_kernel<bf16_t>, dim3((unsigned)nr, p.Cin), dim3(256), lds, stream, p);
+      else
+        hipLaunchKernelGGL(first_wgrad_rows_kernel<float>, dim3((unsigned)nr, p.Cin), dim3(256), lds, stream, p);
+      int rc = check_launch("first_wgrad_rows_kernel");
+      if (rc != UNETDC_OK) return rc;
+      const int n = p.Cin * 9 * p.Cout;
+      hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3((n + 7) / 8), dim3(256), 0, stream, p.part, dw, (int)nr,
+                         p.Cin, p.Cout);
+      return check_launch("first_wgrad_reduce_kernel");
+    }
+  }
   if (dtype == UNETDC_BF16)
     hipLaunchKernelGGL(first_conv_wgrad_kernel<bf16_t>, dim3((unsigned)nb, p.Cin), dim3(256), lds, stream, p);
   else
