@@ -311,27 +311,39 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 template <typename T>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadParams p) {
   constexpr int EPC = Chunk<T>::N;
+  constexpr int UNR = 4;                              // pixels per lane group and trip: four 16-byte loads in flight
   const int cpp = p.C / EPC;                          // lanes per pixel (power of two, <= 64)
   const int ppb = 256 / cpp;
   const int tid = threadIdx.x, cl = tid % cpp, pl = tid / cpp;
   const long HW = (long)p.H * p.W, P = (long)p.N * HW;
   const T* __restrict__ ag = reinterpret_cast<const T*>(p.a);
-  for (long pb = (long)blockIdx.x * ppb; pb < P; pb += (long)gridDim.x * ppb) {
-    const long pix = pb + pl;
-    const bool ok = pix < P;
-    float v[EPC];
-    if (ok) Chunk<T>::unpack(ld16(ag + pix * p.lda + cl * EPC), v);
-    for (int oc = 0; oc < p.OC; ++oc) {
-      float s = 0.f;
-      if (ok) {
+  for (long pb = (long)blockIdx.x * ppb * UNR; pb < P; pb += (long)gridDim.x * ppb * UNR) {
+    float v[UNR][EPC];
+    long pix[UNR];
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) s = fmaf(v[e], p.w[oc * p.C + cl * EPC + e], s);
-      }
-      for (int o = 1; o < cpp; o <<= 1) s += __shfl_xor(s, o, 64);
-      if (ok && cl == 0) {
-        const float z = s + p.b[oc];
-        const long n = pix / HW, rem = pix - n * HW;
-        p.probs[(n * p.OC + oc) * HW + rem] = 1.f / (1.f + expf(-z));
+    for (int u = 0; u < UNR; ++u) {
+      pix[u] = pb + u * ppb + pl;
+      if (pix[u] < P) Chunk<T>::unpack(ld16(ag + pix[u] * p.lda + cl * EPC), v[u]);
+    }
+    for (int oc = 0; oc < p.OC; ++oc) {
+      float wv[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) wv[e] = p.w[oc * p.C + cl * EPC + e];
+      const float bias = p.b[oc];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const bool ok = pix[u] < P;
+        float s = 0.f;
+        if (ok) {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) s = fmaf(v[u][e], wv[e], s);
+        }
+        for (int o = 1; o < cpp; o <<= 1) s += __shfl_xor(s, o, 64);
+        if (ok && cl == 0) {
+          const float z = s + bias;
+          const long n = pix[u] / HW, rem = pix[u] - n * HW;
+          p.probs[(n * p.OC + oc) * HW + rem] = 1.f / (1.f + expf(-z));
+        }
       }
     }
   }
@@ -764,7 +776,7 @@ int launch_head_fwd(HeadParams& p, int dtype, hipStream_t stream) {
   if (rc != UNETDC_OK) return rc;
   UNETDC_REQUIRE(p.b != nullptr, "head: null bias");
   const int epc = dtype == UNETDC_BF16 ? 8 : 4;
-  const int nb = grid_for((long)p.N * p.H * p.W, 256 / (p.C / epc));
+  const int nb = grid_for((long)p.N * p.H * p.W, 4 * (256 / (p.C / epc)));     // UNR = 4 pixels per lane group and trip
   if (dtype == UNETDC_BF16) hipLaunchKernelGGL(head_fwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, stream, p);
   else hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(nb), dim3(256), 0, stream, p);
   return check_launch("head_fwd_kernel");
