@@ -97,6 +97,10 @@ int unetdc_adam_step(const unetdc_adam_desc* table_dev, int n, int64_t total_blo
  * as stored, rows = unetdc_conv3x3_stats_rows(); the buffer must hold rows+64 rows.
  * Cin must be a multiple of 64 (bf16) / 32 (fp32) and Cout of 64: every layer but enc1.0. */
 int unetdc_conv3x3_stats_rows(int64_t npixels, int cout);
+/* Rows of the statistics buffer that carry data after the last unetdc_conv3x3_fwd call of this thread that was asked for
+ * statistics (<= unetdc_conv3x3_stats_rows(): the persistent kernels write one row per workgroup and zeros into the
+ * rest, so summing all rows stays valid; passing this count to unetdc_bn_finalize saves it reading the zero rows). */
+int unetdc_last_stats_rows(void);
 int unetdc_conv3x3_fwd(const void* x, int ldx, const void* w_fwd, const float* bias, const float* scale,
                        const float* shift, void* y, int ldy, float* stats_part, int n, int h, int w, int cin,
                        int cout, int dilation, int dtype, unetdc_stream_t s);

@@ -78,6 +78,12 @@ def test_conv3x3_fwd_dgrad_wgrad(dtype, case):
     yq = y.double()
     np.testing.assert_allclose(stc[0].numpy(), yq.sum(dim=(0, 2, 3)).numpy(), rtol=1e-4, atol=1e-2)
     np.testing.assert_allclose(stc[1].numpy(), (yq * yq).sum(dim=(0, 2, 3)).numpy(), rtol=1e-4, atol=1e-2)
+    # rows that carry data (the persistent kernel writes one row per workgroup and zeros into the rest of the bound)
+    live = _lib.load().unetdc_last_stats_rows()
+    assert 1 <= live <= rows
+    sta = st.cpu()[: rows * 2 * cout].reshape(rows, 2, cout)
+    assert torch.equal(sta[live:], torch.zeros_like(sta[live:]))
+    assert torch.equal(sta[:live].double().sum(0), stc)
     # eval-mode epilogue: relu(acc*scale + shift)
     sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
     y2v = G.empty_nhwc(n * h * w, cout, dtype)

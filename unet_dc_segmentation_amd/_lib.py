@@ -29,6 +29,7 @@ SIGNATURES = {
     "unetdc_pack_many": (I, [P, I, L, I, P]),
     "unetdc_adam_step": (I, [P, I, L, P, D, D, D, D, L, D, I, P]),
     "unetdc_conv3x3_stats_rows": (I, [L, I]),
+    "unetdc_last_stats_rows": (I, []),
     "unetdc_conv3x3_fwd": (I, [P, I, P, P, P, P, P, I, P, I, I, I, I, I, I, I, P]),
     "unetdc_conv3x3_dgrad": (I, [P, I, P, P, I, I, I, I, I, I, I, I, P]),
     "unetdc_conv3x3_wgrad_workspace": (L, [I, I, I, I, I, I]),

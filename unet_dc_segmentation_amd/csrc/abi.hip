@@ -48,6 +48,8 @@ extern "C" {
 int unetdc_version(void) { return UNETDC_ABI_VERSION; }
 const char* unetdc_last_error(void) { return g_err; }
 const char* unetdc_last_kernel(void) { return g_kernel; }
+static thread_local int g_stats_rows = 0;
+int unetdc_last_stats_rows(void) { return g_stats_rows; }
 
 int unetdc_pack_conv3x3(const float* w, void* w_fwd, void* w_dgrad, int cout, int cin, int dtype, unetdc_stream_t s) {
   return launch_pack_conv3x3(w, w_fwd, w_dgrad, cout, cin, dtype, (hipStream_t)s);
@@ -82,7 +84,9 @@ int unetdc_conv3x3_fwd(const void* x, int ldx, const void* w_fwd, const float* b
   p.ntaps = 9; p.stride = 1;
   p.mode = scale ? MODE_AFFINE_RELU : (stats_part ? MODE_STATS : MODE_STORE);
   taps3x3(dilation, p.offy, p.offx);
-  return launch_igemm(p, dtype, (hipStream_t)s);
+  const int rc = launch_igemm(p, dtype, (hipStream_t)s);
+  if (rc == UNETDC_OK && p.mode == MODE_STATS) g_stats_rows = p.mblocks;      // rows that carry data (the rest are zeros)
+  return rc;
 }
 
 int unetdc_conv3x3_dgrad(const void* dy, int lddy, const void* w_dgrad, void* dx, int lddx, int n, int h, int w,
@@ -121,7 +125,7 @@ int unetdc_conv3x3_dgrad_colsum(const void* dy, int lddy, const void* w_dgrad, v
   taps3x3(dilation, p.offy, p.offx);
   int rc = launch_igemm(p, dtype, (hipStream_t)s);
   if (rc != UNETDC_OK) return rc;
-  return launch_stats_colsum(p.stats, igemm_mblocks((long)p.M, cin), cin, c0, c, colsum, (hipStream_t)s);
+  return launch_stats_colsum(p.stats, p.mblocks, cin, c0, c, colsum, (hipStream_t)s);       // rows the kernel wrote
 }
 
 // dgrad whose epilogue also produces the BatchNorm-backward partial sums of the stage that consumes dx
@@ -135,7 +139,7 @@ static int dgrad_bnstats_common(IgemmParams& p, const void* y_prev, int ldy_prev
   p.mode = MODE_BNBWD;
   p.stats = parts; p.bn_y = y_prev; p.bn_ldy = ldy_prev; p.scale = scale; p.shift = shift; p.bn_mean = mean; p.bn_rstd = rstd;
   int rc = launch_igemm(p, dtype, stream);
-  if (rc == UNETDC_OK) { *nparts = rows; return rc; }
+  if (rc == UNETDC_OK) { *nparts = p.mblocks; return rc; }                   // rows that carry data (<= rows; the rest are zeros)
   if (rc != UNETDC_EUNSUPPORTED) return rc;
   // first-generation kernel selected: plain dgrad, then the standalone reduction pass
   p.mode = MODE_STORE; p.stats = nullptr;

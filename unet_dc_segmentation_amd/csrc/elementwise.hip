@@ -886,20 +886,23 @@ int launch_channel_sum(const void* x, int ldx, float* out, void* workspace, long
 // Column sums out of MODE_STATS partial rows [nparts][2][L/2 ... ] (row 0 of each pair = sums of the stored values):
 // out[c] = sum_rows parts[row][0][c0 + c].  Used for the ConvTranspose2d bias gradient, whose input (the first
 // half of the decoder's concat gradient) is written by the dgrad kernel that produced `parts`.
-__global__ void stats_colsum_finalize_kernel(const float* __restrict__ parts, int nparts, int L, int c0, float* out, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void stats_colsum_finalize_kernel(const float* __restrict__ parts, int nparts, int L, int c0,
+                                                                    float* out, int C) {
+  // 32 lanes per channel (rows l, l+32, ... each, fixed shuffle tree): a serial walk over the rows cost 15 us per launch
+  const int c = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
   double s = 0.0;
-  for (int i = 0; i < nparts; ++i) s += (double)parts[(long)i * L + c0 + c];
-  out[c] = (float)s;
+  if (c < C)
+    for (int i = l; i < nparts; i += 32) s += (double)parts[(long)i * L + c0 + c];
+  s = lane32_sum(s);
+  if (c < C && l == 0) out[c] = (float)s;
 }
 
 int launch_stats_colsum(const float* parts, int nparts, int ctotal, int c0, int c, float* out, hipStream_t stream) {
   UNETDC_REQUIRE(parts && out && nparts > 0 && c0 >= 0 && c > 0 && c0 + c <= ctotal, "stats_colsum: bad arguments");
   const float* rp; int rows;
-  int rc = reduce_parts(parts, nparts, 2 * ctotal, &rp, &rows, stream);
+  int rc = reduce_parts(parts, nparts, 2 * ctotal, &rp, &rows, stream, 512);
   if (rc != UNETDC_OK) return rc;
-  hipLaunchKernelGGL(stats_colsum_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, stream, rp, rows, 2 * ctotal, c0, out, c);
+  hipLaunchKernelGGL(stats_colsum_finalize_kernel, dim3((c + 7) / 8), dim3(256), 0, stream, rp, rows, 2 * ctotal, c0, out, c);
   return check_launch("stats_colsum_finalize_kernel");
 }
 

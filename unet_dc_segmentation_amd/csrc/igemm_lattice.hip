@@ -53,6 +53,8 @@ struct LatticeParams {
   int items;                  // N * tiles_per_img * nblocks
   int nkc;                    // Cin / 64
   unsigned mg_nblocks, mg_tpi, mg_tpp, mg_d, mg_tx;   // ceil(2^32 / divisor) for the item decode (exact for n * divisor < 2^32)
+  int stat_rows;              // statistics rows with data = gridDim.x / nblocks (one per workgroup and n-block), 0: per-tile rows
+  int mtiles;                 // N * tiles_per_img = M / 256: rows [stat_rows, mtiles) are written as zeros
   int dbg;                    // UNETDC_LAT_DBG (timing experiments only, results invalid): 1 no tap barriers, 2 no DMA waits, 8 no DMA
 };
 
@@ -267,6 +269,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
       for (int k = 0; k < 4; ++k) { binit[k] = ec.k1[k]; ec.k1[k] = 0.f; }
     }
   };
+  float tot_su = 0.f, tot_sq = 0.f;               // lanes tid < BN: running statistics of channel nblk * BN + tid
   auto epilogue = [&](const Item& it) {
     bool tile_ok[MT];
     unsigned voff[MT], yoff[MT];
@@ -277,9 +280,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
     const unsigned rbytes = 2u * (unsigned)d * ldob, yrbytes = 2u * (unsigned)d * ldyb;   // accumulator rows are 2 lattice pixels apart
     epilogue16c<MODE, MT, true>(p, acc, tile_ok, voff, rbytes, yoff, yrbytes, ec, s4, q4, ypre);
     if (MODE == MODE_STATS || MODE == MODE_BNBWD) {
-      // one partial row per tile (same row count and layout as the other conv kernels); scratch of its own: the stage
-      // and patch buffers carry the next item's prefetch.  The >= 9 tap barriers between two tiles order the reuse.
-      constexpr int nrow = (MODE == MODE_BNBWD) ? 3 : 2;
+      // The per-tile sums are added up per WORKGROUP (gridDim.x is a multiple of nblocks, so a workgroup keeps its n-block
+      // for all its tiles): one partial row per workgroup instead of one per tile -- at 8 x 512 x 512 that is 256-512 rows
+      // instead of 8192, few enough for the BatchNorm finalisers to read directly (no colsum_stage launch in between).
+      // Scratch of its own: the stage and patch buffers carry the next item's prefetch; the >= 9 tap barriers between two
+      // tiles order the reuse.
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         s4[k] += __shfl_xor(s4[k], 16, 64); q4[k] += __shfl_xor(q4[k], 16, 64);
@@ -303,10 +308,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
           su += red[(((w2 * WN + wn2) * 4 + k) * 2 + 0) * 16 + c2];
           sq += red[(((w2 * WN + wn2) * 4 + k) * 2 + 1) * 16 + c2];
         }
-        float* row = p.stats + (long)it.mtile * nrow * p.Cout + it.nblk * BN + tid;
-        row[0] = su;
-        row[p.Cout] = sq;
-        if (nrow == 3) row[2 * p.Cout] = 0.f;
+        tot_su += su;                                       // tiles in the order this workgroup visits them: reproducible
+        tot_sq += sq;
       }
     }
     zero_acc();
@@ -398,6 +401,23 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
     if (nxt.nblk != cur.nblk) { load_consts(nxt.nblk); zero_acc(); }
     cur = nxt;
   }
+  if ((MODE == MODE_STATS || MODE == MODE_BNBWD) && tid < BN) {
+    constexpr int nrow = (MODE == MODE_BNBWD) ? 3 : 2;
+    const int nblk0 = first - (int)udiv((unsigned)first, q.mg_nblocks, (unsigned)q.nblocks) * q.nblocks;
+    const int r0 = (first - nblk0) / q.nblocks;              // this workgroup's row; its n-block never changed
+    float* col = p.stats + nblk0 * BN + tid;
+    float* row = col + (long)r0 * nrow * p.Cout;
+    row[0] = tot_su;
+    row[p.Cout] = tot_sq;
+    if (nrow == 3) row[2 * p.Cout] = 0.f;
+    // rows a per-tile writer would have produced: zeros, so that a reader of all M / 256 rows still gets the right sums
+    for (int r = r0 + q.stat_rows; r < q.mtiles; r += q.stat_rows) {
+      float* z = col + (long)r * nrow * p.Cout;
+      z[0] = 0.f;
+      z[p.Cout] = 0.f;
+      if (nrow == 3) z[2 * p.Cout] = 0.f;
+    }
+  }
 #endif
 }
 
@@ -419,10 +439,20 @@ bool igemm_lattice_supported(const IgemmParams& p, int dtype) {
   if (p.Cin % 64 != 0 || p.Cout % 64 != 0) return false;
   const long HoWo = (long)p.Ho * p.Wo;
   if (p.M % HoWo != 0) return false;
+  {                                               // a workgroup must keep its n-block: nblocks divides the persistent grid
+    const bool wide = p.Cout % 128 == 0;
+    const int nb = p.Cout / (wide ? 128 : 64);
+    if ((256 * (wide ? 1 : 2)) % nb != 0) return false;
+  }
   const long xbytes = (p.M / HoWo) * p.Hi * p.Wi * p.ldx * 2L;
   const long obytes = (long)p.M * p.ldo * 2, ybytes = p.mode == MODE_BNBWD ? (long)p.M * p.bn_ldy * 2 : 0;
   const long wbytes = 9L * p.Cout * p.Cin * 2;
   return xbytes < (1L << 31) && wbytes < (1L << 31) && obytes < (1L << 32) && ybytes < (1L << 32);
+}
+
+static long lattice_grid(long items, int wgs_per_cu) {
+  const long g = 256L * wgs_per_cu;
+  return g > items ? items : g;
 }
 
 template <int WM, int WN, int MT, int NPB, int MODE>
@@ -441,8 +471,11 @@ static int launch_lattice_cfg(IgemmParams& p, const LatticeParams& q, int wgs_pe
     attr_done = true;
   }
   // persistent grid: as many workgroups as fit the chip at once (256 CUs), never more than there are items
-  long grid = 256L * wgs_per_cu;
-  if (grid > q.items) grid = q.items;
+  const long grid = lattice_grid(q.items, wgs_per_cu);
+  if (grid % q.nblocks != 0 || q.stat_rows != (int)(grid / q.nblocks)) {
+    set_error("igemm_lattice: grid %ld / nblocks %d / stat_rows %d inconsistent", grid, q.nblocks, q.stat_rows);
+    return UNETDC_ELAUNCH;
+  }
   hipLaunchKernelGGL((igemm_lattice_kernel<WM, WN, MT, NPB, MODE>), dim3((unsigned)grid), dim3(NW * 64), LDS, stream, p, q);
   char nm[96];
   snprintf(nm, sizeof(nm), "igemm_lattice_kernel<%d, %d, %d, %d, %d>", WM, WN, MT, NPB, MODE);
@@ -476,20 +509,19 @@ int launch_igemm_lattice(IgemmParams& p, hipStream_t stream) {
     q.dbg = dbg;
   }
   const int nimg = (int)((long)p.M / ((long)p.Ho * p.Wo));
-  p.mblocks = nimg * q.tiles_per_img;             // = M / 256: one statistics row per tile
-  if (p.Cout % 128 == 0) {
-    q.nblocks = p.Cout / 128;
-    q.items = p.mblocks * q.nblocks;
-    q.mg_nblocks = magic(q.nblocks); q.mg_tpi = magic(q.tiles_per_img); q.mg_tpp = magic(q.tiles_x * q.tiles_y);
-    q.mg_d = magic(q.d); q.mg_tx = magic(q.tiles_x);
-    p.nblocks = q.nblocks;
-    return launch_lattice_mode<4, 2, 4, 2>(p, q, 1, stream);
-  }
-  q.nblocks = p.Cout / 64;
-  q.items = p.mblocks * q.nblocks;
+  q.mtiles = nimg * q.tiles_per_img;              // = M / 256
+  const bool wide = p.Cout % 128 == 0;
+  const int wgs = wide ? 1 : 2;                   // workgroups per CU of the two configurations
+  q.nblocks = p.Cout / (wide ? 128 : 64);
+  q.items = q.mtiles * q.nblocks;
+  // statistics: one row per workgroup and n-block (the kernel zero-fills the rest of the M / 256 rows).  The grid is
+  // min(items, 256 * wgs): a multiple of nblocks whenever nblocks divides 256 * wgs (every channel count of the networks).
+  q.stat_rows = (int)(lattice_grid(q.items, wgs) / q.nblocks);
+  p.mblocks = q.stat_rows;
   q.mg_nblocks = magic(q.nblocks); q.mg_tpi = magic(q.tiles_per_img); q.mg_tpp = magic(q.tiles_x * q.tiles_y);
   q.mg_d = magic(q.d); q.mg_tx = magic(q.tiles_x);
   p.nblocks = q.nblocks;
+  if (wide) return launch_lattice_mode<4, 2, 4, 2>(p, q, 1, stream);
   return launch_lattice_mode<4, 1, 4, 1>(p, q, 2, stream);
 }
 

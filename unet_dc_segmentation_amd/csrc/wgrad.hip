@@ -179,55 +179,45 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 // independent accumulators, then the four partial sums are added in wave order through LDS.  16-byte
 // coalesced reads, 4x the loads in flight of a thread-per-output loop (which ran the 75 MB of slabs of a
 // tap-fused layer at 1.6 TB/s); the summation order is fixed, so the result is bitwise reproducible.
+// (A variant with all taps of four (co, ci) pairs per lane -- contiguous 144-byte output runs -- has 9x fewer blocks:
+// 16 blocks for a 64 x 64 layer walking 512 slabs each; it measured 82 us per launch against 18 us.)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                            int ksplit, int ntaps, int CI, int CJ) {
-  // A lane owns FOUR consecutive (co, ci) pairs and ALL taps of them: it reads one float4 per (slab, tap) -- 16-byte
-  // coalesced -- and writes 4 * ntaps CONSECUTIVE floats of the PyTorch layout [co][ci][taps] (the first version wrote
-  // one tap per lane: 4-byte stores 36 bytes apart).  The four wave groups of a block take every fourth slab; their
-  // partial sums are added in group order through LDS, so the summation order is fixed (bitwise reproducible).
-  __shared__ float4 red[3][9][64];
+  __shared__ float4 red[4][64];
   const long n = (long)CI * CJ;
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const long q = (long)blockIdx.x * 64 + lane;             // float4 index into one [n] plane
-  const bool live = q * 4 < n;
-  float4 a[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t) a[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (live) {
-    const long plane4 = n / 4;
-    for (int ks = g; ks < ksplit; ks += 4) {
-      const float4* src = reinterpret_cast<const float4*>(part) + (long)ks * ntaps * plane4 + q;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        if (t < ntaps) {
-          const float4 v = src[(long)t * plane4];
-          a[t].x += v.x; a[t].y += v.y; a[t].z += v.z; a[t].w += v.w;
-        }
-      }
+  const long q = (long)blockIdx.x * 64 + lane;             // float4 index into one slab [ntaps][n]
+  const long total4 = n * ntaps / 4;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  if (q < total4) {
+    const float4* src = reinterpret_cast<const float4*>(part) + q;
+    const long stride4 = total4;
+    int ks = g;
+    for (; ks + 4 < ksplit; ks += 8) {
+      const float4 u = src[(long)ks * stride4], v = src[(long)(ks + 4) * stride4];
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+      b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+    }
+    if (ks < ksplit) {
+      const float4 u = src[(long)ks * stride4];
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
     }
   }
-  if (g > 0) {
-#pragma unroll
-    for (int t = 0; t < 9; ++t) red[g - 1][t][lane] = a[t];
-  }
+  red[g][lane] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
   __syncthreads();
-  if (g == 0 && live) {
-    float* dst = out + q * 4 * ntaps;
-    float o[36];
+  if (g == 0 && q < total4) {
+    float4 s = red[0][lane];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      float4 s = a[t];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { const float4 v = red[k][t][lane]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
-      if (t < ntaps) { o[t] = s.x; o[ntaps + t] = s.y; o[2 * ntaps + t] = s.z; o[3 * ntaps + t] = s.w; }
+    for (int k = 1; k < 4; ++k) {
+      s.x += red[k][lane].x; s.y += red[k][lane].y; s.z += red[k][lane].z; s.w += red[k][lane].w;
     }
-    if (ntaps == 9) {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) reinterpret_cast<float4*>(dst)[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
-    } else {                                               // ConvTranspose2d: 4 taps
-#pragma unroll
-      for (int k = 0; k < 4; ++k) reinterpret_cast<float4*>(dst)[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
-    }
+    const long e = q * 4;
+    const int t = (int)(e / n);
+    const long ij = e - (long)t * n;
+    out[ij * ntaps + t] = s.x;
+    out[(ij + 1) * ntaps + t] = s.y;
+    out[(ij + 2) * ntaps + t] = s.z;
+    out[(ij + 3) * ntaps + t] = s.w;
   }
 }
 
@@ -357,7 +347,7 @@ int launch_wgrad(WgradParams& p, float* out, void* workspace, long workspace_byt
                                 p.CJ, p.offy[8], dtype, &units, stream);
     if (rc != UNETDC_OK) return rc;
     const long n = (long)p.CI * p.CJ * p.ntaps;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(((long)p.CI * p.CJ / 4 + 63) / 64)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, stream,
                        reinterpret_cast<float*>(workspace), out, units, p.ntaps, p.CI, p.CJ);
     return check_launch("wgrad_reduce_kernel");
   }
@@ -386,7 +376,7 @@ int launch_wgrad(WgradParams& p, float* out, void* workspace, long workspace_byt
     rc = wide ? launch_w<float, 2>(p, stream) : launch_w<float, 1>(p, stream);
   if (rc != UNETDC_OK) return rc;
   const long n = (long)p.CI * p.CJ * p.ntaps;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(((long)p.CI * p.CJ / 4 + 63) / 64)), dim3(256), 0, stream, p.part, out,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, stream, p.part, out,
                      p.ksplit, p.ntaps, p.CI, p.CJ);
   return check_launch("wgrad_reduce_kernel");
 }

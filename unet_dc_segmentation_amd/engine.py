@@ -272,6 +272,7 @@ class UNetEngine:
                 call("unetdc_conv3x3_fwd", xin.data_ptr(), xin.stride(0), st.w_fwd.data_ptr(), conv.bias.data_ptr(),
                      None, None, y.data_ptr(), y.stride(0), st.stats.data_ptr(), N, h, w, st.cin, st.cout,
                      st.dil, self.dt, s)
+                st.stat_rows = _lib.load().unetdc_last_stats_rows()     # rows that carry data (<= the sizing bound)
             track = bn.track_running_stats and bn.running_mean is not None
             mom = BN_MOMENTUM if bn.momentum is None else bn.momentum
             call("unetdc_bn_finalize", st.stats.data_ptr(), st.stat_rows, st.npix, bn.weight.data_ptr(),
