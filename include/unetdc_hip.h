@@ -236,6 +236,12 @@ int unetdc_channel_sum(const void* x, int ldx, float* out, void* workspace, int6
  *   only the first max_out are written).  All outputs are DEVICE pointers.  Exact integer arithmetic, order-independent. */
 int unetdc_mask_from_probs(const float* probs, int ph, int pw, float thresh, uint8_t* mask, int oh, int ow,
                            unetdc_stream_t s);
+/* The mask the reference's call actually produces: `cv2.resize(mask512, (ow, oh), cv2.INTER_NEAREST)`
+ * (/root/reference/quantify_droplets_batch.py:57) passes the flag in the positional slot of `dst`, so OpenCV's default
+ * 8-bit INTER_LINEAR runs on the {0,1} mask.  Tables as for unetdc_resize_linear_u8_to_chw_f32. */
+int unetdc_mask_from_probs_linear(const float* probs, int ph, int pw, float thresh, uint8_t* mask, int oh, int ow,
+                                  const int32_t* xofs, const int16_t* xcoef, const int32_t* yofs, const int16_t* ycoef,
+                                  unetdc_stream_t s);
 int64_t unetdc_ccl_workspace(int h, int w);
 int unetdc_ccl_stats(const uint8_t* mask, int h, int w, int min_area, void* workspace, int64_t workspace_bytes,
                      int32_t* out_count, int32_t* out_area, int64_t* out_sumy, int64_t* out_sumx, int32_t* out_root,

@@ -12,8 +12,9 @@ PyTorch-CPU exactly like the reference.  On the GPU the threshold, the nearest-n
 size, the connected-component labelling and the per-droplet sums run on the device as well
 (unet_dc_segmentation_amd/droplets.py, csrc/ccl.hip): only the uint8 mask and three integers per droplet are
 copied back.  cv2 / scikit-image are optional on the CPU path: SciPy's ``ndimage.label`` with its default
-cross-shaped structure is skimage's ``label(connectivity=1)``, and the nearest-neighbour resize restates cv2's
-index rule (PIL's NEAREST samples pixel centres and picks different source pixels).
+cross-shaped structure is skimage's ``label(connectivity=1)``; the resize of the mask to the original size reproduces what the
+reference's call computes (its interpolation flag sits in the positional slot of ``dst``, so OpenCV's default 8-bit bilinear
+runs on the {0,1} mask: unet_dc_segmentation_amd/droplets.py:MASK_RESIZE).
 """
 import argparse
 from pathlib import Path
@@ -24,7 +25,7 @@ import torch
 from PIL import Image
 
 from models.model_2 import UNetDC
-from unet_dc_segmentation_amd.droplets import resize_nearest_cv2
+from unet_dc_segmentation_amd.droplets import resize_mask_like_reference
 from utils.data_loader import resize_image, rolling_ball_correction_rgb
 
 DEVICE = "cuda" if torch.cuda.is_available() else "cpu"
@@ -105,7 +106,7 @@ def run_batch(tensors, meta, model, mask_dir, overlay_dir, thresh, min_area, px_
         if on_device:
             mask, df = quantify_device(probs[i, 0], thresh, (oh, ow), min_area, px_per_um)
         else:
-            mask = resize_nearest_cv2(masks512[i], ow, oh)
+            mask = resize_mask_like_reference(masks512[i], ow, oh)
             df = quantify(mask, min_area, px_per_um)
         Image.fromarray(mask * 255).save(str(mask_dir / f"{name}_pred.png"))
         df.insert(0, "filename", Path(fpath).name) if not df.empty else None

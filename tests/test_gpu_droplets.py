@@ -83,11 +83,17 @@ def test_ccl_table_matches_scipy(case, min_area):
         np.testing.assert_allclose(df["equivalent_diameter"].to_numpy(), ref["equivalent_diameter"].to_numpy(), rtol=1e-15)
 
 
+@pytest.mark.parametrize("mode", ["nearest", "reference"])
 @pytest.mark.parametrize("out_hw", [(512, 512), (276, 408), (1037, 1388), (97, 33)])
-def test_threshold_is_strict_and_resize_follows_cv2_rule(out_hw):
-    """mask = cv2.resize((p > thresh).astype(uint8), (ow, oh), INTER_NEAREST): strict compare on the fp32 value
-    (a probability exactly at the threshold is background) and source index min(floor(d * src / dst), src - 1)."""
-    from unet_dc_segmentation_amd.droplets import mask_and_droplets, resize_nearest_cv2
+def test_threshold_is_strict_and_resize_follows_cv2_rule(out_hw, mode, monkeypatch):
+    """nearest: mask = cv2.resize((p > thresh).astype(uint8), (ow, oh), interpolation=INTER_NEAREST): strict compare on the
+    fp32 value (a probability exactly at the threshold is background), source index min(floor(d * src / dst), src - 1).
+    reference (the default): what the reference's positional-flag call computes, OpenCV's 8-bit INTER_LINEAR on the {0,1}
+    mask (utils/data_loader.py:resize_linear_cv2_u8 restates it; both rules unpinned against cv2, which is not installed)."""
+    from unet_dc_segmentation_amd import droplets
+    from unet_dc_segmentation_amd.droplets import mask_and_droplets, resize_mask_like_reference
+    monkeypatch.setattr(droplets, "MASK_RESIZE", mode)
+    resize_nearest_cv2 = resize_mask_like_reference
     g = torch.Generator().manual_seed(5)
     p = torch.rand(512, 512, generator=g)
     thresh = float(np.float32(0.3))

@@ -18,6 +18,9 @@ SWITCH_SETS = {
     "per_tap_dma_32x32": {"UNETDC_IGEMM": "dma", "UNETDC_WGRAD": "dma", "UNETDC_MFMA16": "0"},
     "fused_without_ring_unfused_epilogues": {"UNETDC_WGRAD_RING": "0", "UNETDC_MFMA16": "0", "UNETDC_FUSE_BNBWD": "0",
                                              "UNETDC_FUSE_COLSUM": "0", "UNETDC_FUSED_LOSS": "0"},
+    # round-2 kernels off: halo-patch / per-tap convolutions instead of the persistent lattice kernel, quadrant ring and
+    # per-tap weight gradients instead of the tap-split ring and the valid-rectangle kernel, per-pixel first-layer wgrad
+    "round1_kernels": {"UNETDC_LATTICE": "0", "UNETDC_WGRAD_SPLIT": "0", "UNETDC_WGRAD_RECT": "0", "UNETDC_FIRST_ROWS": "0"},
 }
 
 

@@ -7,7 +7,7 @@ set -e
 python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err                      # default run (with cpu_baseline)
 python3 tools/show_bench.py gpurun_out/${tag}_bench.json
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --per-layer > gpurun_out/${tag}_bench_nocpu.json 2> gpurun_out/${tag}_per_layer.txt
-bash tools/rocprof_stats.sh ${tag} > gpurun_out/${tag}_stats_summary.txt 2>&1
+bash tools/rocprof_stats.sh ${tag}_prof > gpurun_out/${tag}_stats_summary.txt 2>&1
 head -3 gpurun_out/${tag}_stats_summary.txt
 bash tools/pmc_traffic.sh ${tag} > gpurun_out/${tag}_pmc_log.txt 2>&1 || tail -5 gpurun_out/${tag}_pmc_log.txt
 python3 bench.py --mode infer --dtype f32 --steps 20 --warmup 5 > gpurun_out/${tag}_bench_infer_f32.json 2>/dev/null

@@ -64,6 +64,7 @@ SIGNATURES = {
     "unetdc_rolling_ball_u8": (I, [P, P, I, I, I, I, P, L, P]),
     "unetdc_resize_linear_u8_to_chw_f32": (I, [P, I, I, I, P, I, I, P, P, P, P, P]),
     "unetdc_mask_from_probs": (I, [P, I, I, F, P, I, I, P]),
+    "unetdc_mask_from_probs_linear": (I, [P, I, I, F, P, I, I, P, P, P, P, P]),
     "unetdc_ccl_workspace": (L, [I, I]),
     "unetdc_ccl_stats": (I, [P, I, I, I, P, L, P, P, P, P, P, I, P]),
 }

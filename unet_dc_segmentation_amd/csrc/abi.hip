@@ -380,6 +380,12 @@ int unetdc_mask_from_probs(const float* probs, int ph, int pw, float thresh, uin
   return launch_mask_from_probs(probs, ph, pw, thresh, mask, oh, ow, (hipStream_t)s);
 }
 
+int unetdc_mask_from_probs_linear(const float* probs, int ph, int pw, float thresh, uint8_t* mask, int oh, int ow,
+                                  const int32_t* xofs, const int16_t* xcoef, const int32_t* yofs, const int16_t* ycoef,
+                                  unetdc_stream_t s) {
+  return launch_mask_from_probs_linear(probs, ph, pw, thresh, mask, oh, ow, xofs, xcoef, yofs, ycoef, (hipStream_t)s);
+}
+
 int64_t unetdc_ccl_workspace(int h, int w) { return ccl_workspace_bytes(h, w); }
 
 int unetdc_ccl_stats(const uint8_t* mask, int h, int w, int min_area, void* workspace, int64_t workspace_bytes,

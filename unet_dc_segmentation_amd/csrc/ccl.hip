@@ -192,6 +192,38 @@ int launch_mask_from_probs(const float* probs, int ph, int pw, float thresh, uns
   return check_launch("mask_kernel");
 }
 
+// The reference calls cv2.resize(mask512, (ow, oh), cv2.INTER_NEAREST) (quantify_droplets_batch.py:57): the third positional
+// parameter of cv2.resize is `dst`, so the flag is ignored and OpenCV's default 8-bit INTER_LINEAR runs on the {0,1} mask:
+//   r = m[x0] * a0 + m[x1] * a1 (11-bit coefficients), v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2  in {0,1}
+// Same tables as unetdc_resize_linear_u8_to_chw_f32 (utils/data_loader.py:linear_tables + the edge rule).
+__global__ void mask_linear_kernel(const float* __restrict__ probs, int ph, int pw, float thresh, unsigned char* __restrict__ mask,
+                                   int oh, int ow, const int* __restrict__ xofs, const short* __restrict__ xa,
+                                   const int* __restrict__ yofs, const short* __restrict__ ya) {
+  const long n = (long)oh * ow;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int dy = (int)(i / ow), dx = (int)(i - (long)dy * ow);
+    const int sx0 = xofs[dx], sx1 = sx0 + 1 < pw ? sx0 + 1 : pw - 1;
+    int sy0 = yofs[dy], sy1 = sy0 + 1;
+    sy0 = sy0 < 0 ? 0 : (sy0 > ph - 1 ? ph - 1 : sy0);
+    sy1 = sy1 < 0 ? 0 : (sy1 > ph - 1 ? ph - 1 : sy1);
+    const int a0 = xa[2 * dx], a1 = xa[2 * dx + 1], b0 = ya[2 * dy], b1 = ya[2 * dy + 1];
+    const int m00 = probs[(long)sy0 * pw + sx0] > thresh, m01 = probs[(long)sy0 * pw + sx1] > thresh;
+    const int m10 = probs[(long)sy1 * pw + sx0] > thresh, m11 = probs[(long)sy1 * pw + sx1] > thresh;
+    const int r0 = m00 * a0 + m01 * a1, r1 = m10 * a0 + m11 * a1;
+    const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    mask[i] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+  }
+}
+
+int launch_mask_from_probs_linear(const float* probs, int ph, int pw, float thresh, unsigned char* mask, int oh, int ow,
+                                  const int* xofs, const short* xcoef, const int* yofs, const short* ycoef, hipStream_t stream) {
+  UNETDC_REQUIRE(probs && mask && xofs && xcoef && yofs && ycoef && ph > 0 && pw > 0 && oh > 0 && ow > 0,
+                 "mask_from_probs_linear: bad arguments");
+  hipLaunchKernelGGL(mask_linear_kernel, dim3(ccl_grid((long)oh * ow)), dim3(256), 0, stream, probs, ph, pw, thresh, mask, oh, ow,
+                     xofs, xcoef, yofs, ycoef);
+  return check_launch("mask_linear_kernel");
+}
+
 long ccl_workspace_bytes(int h, int w) {
   const long n = (long)h * w, nb = (n + CCL_BLK - 1) / CCL_BLK;
   return n * (4 + 4 + 8 + 8) + (nb + 16) * 4 + 64;

@@ -128,6 +128,8 @@ int launch_channel_sum(const void* x, int ldx, float* out, void* workspace, long
 // ccl.hip: droplet quantification
 int launch_mask_from_probs(const float* probs, int ph, int pw, float thresh, unsigned char* mask, int oh, int ow,
                            hipStream_t stream);
+int launch_mask_from_probs_linear(const float* probs, int ph, int pw, float thresh, unsigned char* mask, int oh, int ow,
+                                  const int* xofs, const short* xcoef, const int* yofs, const short* ycoef, hipStream_t stream);
 long ccl_workspace_bytes(int h, int w);
 int launch_ccl_stats(const unsigned char* mask, int h, int w, int min_area, void* workspace, long workspace_bytes,
                      int* out_count, int* out_area, long long* out_sumy, long long* out_sumx, int* out_root, int max_out,

@@ -22,6 +22,22 @@ def resize_nearest_cv2(mask, ow, oh):
     return mask[nearest_index(oh, mask.shape[0])[:, None], nearest_index(ow, mask.shape[1])[None, :]]
 
 
+# How the 512 x 512 mask gets to the original image size.  The reference writes
+#     cv2.resize(mask512, (ow, oh), cv2.INTER_NEAREST)                    (/root/reference/quantify_droplets_batch.py:57)
+# with the flag in the positional slot of `dst`: OpenCV ignores it and runs its default 8-bit INTER_LINEAR on the {0,1} mask.
+# "reference" reproduces what that call computes, "nearest" what it names.  (cv2 is not installed here: both rules are
+# restatements -- utils/data_loader.py:resize_linear_cv2_u8 and resize_nearest_cv2 below -- parity unpinned against cv2.)
+MASK_RESIZE = "reference"
+
+
+def resize_mask_like_reference(mask, ow, oh):
+    """CPU path: uint8 {0,1} mask [h, w] -> [oh, ow] under MASK_RESIZE."""
+    if MASK_RESIZE == "nearest" or (mask.shape[0] == oh and mask.shape[1] == ow):
+        return resize_nearest_cv2(mask, ow, oh)
+    from utils.data_loader import resize_linear_cv2_u8
+    return resize_linear_cv2_u8(np.ascontiguousarray(mask, dtype=np.uint8), ow, oh)
+
+
 def mask_and_droplets(probs2d, thresh, out_hw, min_area, max_droplets=1 << 16):
     """probs2d: [H, W] fp32 probabilities on the HIP device.  Returns (mask uint8 [oh, ow] DEVICE tensor,
     area int64 [n], centroid_row float64 [n], centroid_col float64 [n]) -- droplets in the reference's label order."""
@@ -33,7 +49,14 @@ def mask_and_droplets(probs2d, thresh, out_hw, min_area, max_droplets=1 << 16):
     dev = probs2d.device
     s = torch.cuda.current_stream().cuda_stream
     mask = torch.empty(oh, ow, dtype=torch.uint8, device=dev)
-    _lib.call("unetdc_mask_from_probs", probs2d.data_ptr(), ph, pw, float(thresh), mask.data_ptr(), oh, ow, s)
+    if MASK_RESIZE == "nearest" or (ph == oh and pw == ow):          # same size: both rules are the identity
+        _lib.call("unetdc_mask_from_probs", probs2d.data_ptr(), ph, pw, float(thresh), mask.data_ptr(), oh, ow, s)
+    else:
+        from .preprocess import _resize_tables
+        xo, xa = _resize_tables(pw, ow, dev, True)
+        yo, ya = _resize_tables(ph, oh, dev, False)
+        _lib.call("unetdc_mask_from_probs_linear", probs2d.data_ptr(), ph, pw, float(thresh), mask.data_ptr(), oh, ow,
+                  xo.data_ptr(), xa.data_ptr(), yo.data_ptr(), ya.data_ptr(), s)
     nbytes = _lib.load().unetdc_ccl_workspace(oh, ow)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     cap = int(min(max_droplets, oh * ow))
