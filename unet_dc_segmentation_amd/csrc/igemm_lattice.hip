@@ -179,8 +179,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
                  : 32u;
   };
   auto issue_slice = [&](int sl, int buf, unsigned pbase, unsigned edges) {
-    const unsigned f = (pflg[sl >> 2] >> (8 * (sl & 3))) & edges;
-    lds_dma16(xr, lds_base + buf * PBUF + (wave + NW * sl) * 1024, f ? LOOB : prel[sl], pbase);
+    const int pr = (wave + NW * sl) * 8 + sub;
+    const int ppy = (pr * 1928) >> 16, ppx = pr - ppy * LPW;       // pr / 34 for pr < 1024
+    const int ch = pc ^ ((ppx >> 1) & 7);
+    const unsigned rel = (unsigned)(((ppy * d) * p.Wi + ppx * d) * p.ldx * 2 + ch * 16);
+    const unsigned f = ((ppy == 0 ? 1u : 0u) | (ppy == LPH - 1 ? 2u : 0u) | (ppx == 0 ? 4u : 0u) | (ppx == LPW - 1 ? 8u : 0u) |
+                        (pr >= LPP ? 16u : 0u) | 32u) & edges;
+    lds_dma16(xr, lds_base + buf * PBUF + (wave + NW * sl) * 1024, f ? LOOB : rel, pbase);
   };
   auto issue_w = [&](int stage, int tap, int kc, int nblk, bool valid) {
     const unsigned soff = (unsigned)(((tap * p.Cout + nblk * BN) * p.Cin + kc * 64) * 2);
@@ -422,6 +427,327 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// Wide-wave form: 4 waves, each owns 64 pixels x 128 channels (two 64-channel groups: 4 M tiles x 8 N tiles).
+// SQ counters of the 64 x 64 wave tile: 0.5 ds_read_b128 per MFMA = 128 B/clk/CU with all four SIMDs busy, i.e. the LDS peak
+// before any DMA write.  Here a wave reads 4 A + 8 B fragments for 32 MFMAs (0.375 per MFMA) and the patch is shared by
+// 128 output channels.  To keep TWO workgroups per CU (4 waves each; the single patch buffer leaves the next chunk's
+// patch exposed, the other workgroup covers it) the weight ring has two 16 KB stages: 44 KB patch + 32 KB + 4 KB scratch
+// = 80 KB.  With two stages the weights of tap t+1 are issued behind the barrier of tap t (one tap = 64 MFMAs per wave
+// = the same 1024 cycles of cover as two taps of the 3-stage form); the stage of flat step q is q & 1, and 9 taps per
+// chunk flip the parity per chunk (two fragment base sets, selected at compile time inside the unrolled taps).
+// Modes: STORE / STATS / AFFINE_RELU (the fused BatchNorm-backward epilogue keeps the 64-wide forms: its saved-output
+// prefetch does not fit the register budget next to 128 accumulators).
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void igemm_lattice_wide_kernel(const IgemmParams p, const LatticeParams q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int WM = 4, WN = 1, MT = 4, NPB = 1, NG = 2;
+  constexpr int NW = WM * WN, BN = WN * NG * 64;
+  constexpr int BI = BN / 8 / NW;                 // weight DMA instructions per wave per tap
+  constexpr int PJ = (LPI + NW - 1) / NW;         // patch DMA instructions per wave per chunk (uniform: padded)
+  constexpr int SPT = (NW == 4) ? 3 : 2;          // patch slices per tap while prefetching
+  constexpr int PBUF = PJ * NW * 1024;            // bytes per patch buffer
+  constexpr int WST = BN * 128;                   // bytes per weight stage
+  constexpr int OFF_W = NPB * PBUF, OFF_RED = OFF_W + 2 * WST;
+  constexpr int NST = MT * 4 * NG;                // epilogue stores per wave and tile
+  static_assert(WM * MT == 16 && (MT % 2) == 0, "a workgroup owns 16 M-tiles = 8 rows x 32 pixels");
+  static_assert(BN % (8 * NW) == 0, "weight rows / wave mismatch");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const unsigned lds_base = lds_addr_of(smem);
+  const int G = gridDim.x;
+  const int d = q.d;
+
+  // The patch origin (-1, -1) of a border tile lies in front of the tensor; the scalar part of a DMA address (soffset)
+  // cannot be negative, so the descriptor starts SH bytes early (those bytes are never touched: halo lanes outside the
+  // image carry an out-of-range voffset and read zeros).
+  const unsigned SH = (unsigned)((d * p.Wi + d) * p.ldx * 2);
+  const unsigned xbytes = (unsigned)((long)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.ldx * 2) + SH;
+  const unsigned wbytes = (unsigned)((long)9 * p.Cout * p.Cin * 2);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.x)) - SH, 0, xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, wbytes, 0x00020000);
+
+  // ---- per-lane constants --------------------------------------------------------------------------------------
+  const int sub = lane >> 3, pc = lane & 7;
+  // patch slice sl of this wave = DMA instruction wave + NW*sl = patch pixels 8*instr .. 8*instr+7 (row-major in the
+  // 10 x 34 patch); this lane feeds pixel pr, physical chunk pc <- logical chunk pc ^ key(column)
+  // (this form recomputes the lane's piece offset and border flags per slice when it issues the DMA -- 11 slices per chunk,
+  //  a few dozen VALU instructions against 576 MFMAs -- instead of holding 14 registers across the tap loop: with 128
+  //  accumulators they were spilled, and a scratch reload drains the VM counter in front of the hand-placed DMAs)
+  // weight rows: LDS row lrow of the stage = N tile (q >> 4) of its 64-channel group, column q & 15
+  //   <-> output channel 4*(q & 15) + (q >> 4): the four N tiles of a lane hold four consecutive channels
+  unsigned bbase[BI];
+#pragma unroll
+  for (int j = 0; j < BI; ++j) {
+    const int lrow = (wave + NW * j) * 8 + sub;
+    const int grp = lrow >> 6, qq = lrow & 63;
+    const int cc = (qq & 15) * 4 + (qq >> 4);
+    const int c = pc ^ ((lrow >> 1) & 7);
+    bbase[j] = (unsigned)((grp * 64 + cc) * p.Cin * 2 + c * 16);
+  }
+  // fragment read bases.  MFMA row m of a tile (supplied by lanes with c16 = m) is pixel PI(m) of the 16:
+  // lanes 0-3,12-15 -> even pixels, lanes 4-11 -> odd pixels
+  const int c16 = lane & 15, rb = lane >> 4;
+  const int pi = (c16 < 4) ? 2 * c16 : (c16 < 12 ? 2 * (c16 - 4) + 1 : 2 * (c16 - 8));
+  int aoff[3][2], boff[2];                        // boff: group 0; group 1 = + 64 * 128
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int px = kx + pi;                     // patch column (mod 16: +16 for the right half keeps the key)
+      aoff[kx][g] = (wm * (MT / 2) * LPW + px) * 128 + (((4 * g + rb) ^ ((px >> 1) & 7)) << 4);
+    }
+#pragma unroll
+  for (int g = 0; g < 2; ++g) boff[g] = OFF_W + (wn * 64 + c16) * 128 + (((4 * g + rb) ^ ((c16 >> 1) & 7)) << 4);
+
+  // ---- work items ---------------------------------------------------------------------------------------------------
+  struct Item { int img, phy, phx, ly0, lx0, nblk, mtile; };
+  // v_mul_hi_u32 is a VALU instruction: readfirstlane brings the (wave-uniform) quotient back to an SGPR, which is what
+  // the scalar operands of the DMA statements need
+  auto udiv = [](unsigned n, unsigned magic, unsigned dv) {
+    return dv == 1 ? n : (unsigned)__builtin_amdgcn_readfirstlane((int)__umulhi(n, magic));
+  };
+  auto decode = [&](int item) {
+    Item it;
+    it.mtile = (int)udiv((unsigned)item, q.mg_nblocks, (unsigned)q.nblocks);
+    it.nblk = item - it.mtile * q.nblocks;
+    it.img = (int)udiv((unsigned)it.mtile, q.mg_tpi, (unsigned)q.tiles_per_img);
+    int r = it.mtile - it.img * q.tiles_per_img;
+    const int tpp = q.tiles_x * q.tiles_y;        // tiles per phase
+    const int ph = (int)udiv((unsigned)r, q.mg_tpp, (unsigned)tpp);
+    r -= ph * tpp;
+    it.phy = (int)udiv((unsigned)ph, q.mg_d, (unsigned)d);
+    it.phx = ph - it.phy * d;
+    const int ty = (int)udiv((unsigned)r, q.mg_tx, (unsigned)q.tiles_x);
+    it.ly0 = ty * LTH;
+    it.lx0 = (r - ty * q.tiles_x) * LTW;
+    return it;
+  };
+  const int first = xcd_remap(blockIdx.x, G);
+  if (first >= q.items) return;                   // (grid <= items: never taken)
+
+  // ---- DMA issue -----------------------------------------------------------------------------------------------------
+  // scalar description of the patch of (item, K chunk): byte offset of its origin (+SH) and which borders it touches
+  auto patch_base = [&](const Item& it, int kc) {
+    return (unsigned)((((it.img * p.Hi + (it.ly0 - 1) * d + it.phy) * p.Wi + (it.lx0 - 1) * d + it.phx) * p.ldx) * 2 + kc * 128) + SH;
+  };
+  auto patch_edges = [&](const Item& it, bool valid) {
+    return valid ? ((it.ly0 == 0 ? 1u : 0u) | (it.ly0 + LTH == q.Hs ? 2u : 0u) | (it.lx0 == 0 ? 4u : 0u) |
+                    (it.lx0 + LTW == q.Ws ? 8u : 0u) | 16u)
+                 : 32u;
+  };
+  auto issue_slice = [&](int sl, int buf, unsigned pbase, unsigned edges) {
+    int sub_here = sub;
+    asm volatile("" : "+v"(sub_here));              // opaque: keeps the compiler from hoisting (and then spilling) the 11 results
+    const int pr = (wave + NW * sl) * 8 + sub_here;
+    const int ppy = (pr * 1928) >> 16, ppx = pr - ppy * LPW;       // pr / 34 for pr < 1024
+    const int ch = pc ^ ((ppx >> 1) & 7);
+    const unsigned rel = (unsigned)(((ppy * d) * p.Wi + ppx * d) * p.ldx * 2 + ch * 16);
+    const unsigned f = ((ppy == 0 ? 1u : 0u) | (ppy == LPH - 1 ? 2u : 0u) | (ppx == 0 ? 4u : 0u) | (ppx == LPW - 1 ? 8u : 0u) |
+                        (pr >= LPP ? 16u : 0u) | 32u) & edges;
+    lds_dma16(xr, lds_base + buf * PBUF + (wave + NW * sl) * 1024, f ? LOOB : rel, pbase);
+  };
+  auto issue_w = [&](int stage, int tap, int kc, int nblk, bool valid) {
+    const unsigned soff = (unsigned)(((tap * p.Cout + nblk * BN) * p.Cin + kc * 64) * 2);
+#pragma unroll
+    for (int j = 0; j < BI; ++j)
+      lds_dma16(wr, lds_base + OFF_W + stage * WST + (wave + NW * j) * 1024, valid ? bbase[j] : LOOB, soff);
+  };
+
+  f32x4 acc[NG][MT][4];
+  float binit[NG][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};    // conv bias of this lane's channels: the accumulators START from it
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int ng = 0; ng < NG; ++ng)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[ng][i][j][e] = binit[ng][j];
+  };
+
+  // one tap: per 32-channel half 4 A + 8 B fragments, 32 MFMAs (the A fragments stay, the B fragments of the two 64-channel
+  // groups take turns in one register set)
+  auto compute_tap = [&](int ky, int kx, const int (&bb)[2], const int (&ab)[3][2]) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      u32x4 fa[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) fa[i] = ld16(smem + ab[kx][g] + ((i >> 1) + ky) * (LPW * 128) + (i & 1) * (16 * 128));
+#pragma unroll
+      for (int ng = 0; ng < NG; ++ng) {
+        u32x4 fb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = ld16(smem + bb[g] + (ng * 4 + j) * 16 * 128);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[ng][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]),
+                                                                    __builtin_bit_cast(bf16x8, fb[j]), acc[ng][i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---- epilogue of one item -----------------------------------------------------------------------------------------------
+  const unsigned ldob = (unsigned)(p.ldo * 2), ldyb = (unsigned)(p.bn_ldy * 2);
+  const int xb = (rb == 0) ? 0 : (rb == 1 ? 1 : (rb == 2 ? 9 : 8));          // pixel of accumulator row 4*rb + v = xb + 2v
+  // MODE_BNBWD: the consumer stage's saved conv outputs of this item, fetched YT taps before the item's last MFMA.  They
+  // sit in the VM queue between the weight DMAs: the counted waits of the two taps after the fetch leave them in flight
+  // (+NY), from the third tap on an in-order wait would require them -- so the fetch goes at tap 6 of the last chunk.
+  // MODE_BNBWD: no prefetch of the saved outputs and no resident per-channel constants here (64 + 32 registers next to 128
+  // accumulators): the epilogue loads both itself; that latency is what the second workgroup of the CU is for.
+  auto item_offsets = [&](const Item& it, unsigned (&voff)[MT], unsigned (&yoff)[MT]) {
+    const int col = it.nblk * BN + 4 * c16;                                  // group 0; group 1: + 64 channels
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int gm = wm * MT + i;                                            // M tile of the workgroup: row gm >> 1, half gm & 1
+      const int Y = (it.ly0 + (gm >> 1)) * d + it.phy, X = (it.lx0 + 16 * (gm & 1) + xb) * d + it.phx;
+      const unsigned pix = (unsigned)((it.img * p.Ho + Y) * p.Wo + X);
+      voff[i] = pix * ldob + (unsigned)(col * 2);
+      yoff[i] = pix * ldyb + (unsigned)(col * 2);
+    }
+  };
+  Epi16Consts ec[NG];
+  auto load_consts = [&](int nblk) {
+#pragma unroll
+    for (int ng = 0; ng < NG; ++ng) {
+      if (MODE == MODE_BNBWD) continue;                    // loaded per item in the epilogue
+      ec[ng] = epi16_consts<MODE>(p, nblk * BN + ng * 64 + 4 * c16);
+      if (MODE == MODE_STORE || MODE == MODE_STATS) {      // "+ bias" modes: fold it into the accumulator init
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { binit[ng][k] = ec[ng].k1[k]; ec[ng].k1[k] = 0.f; }
+      }
+    }
+  };
+  float tot_su = 0.f, tot_sq = 0.f;               // lanes tid < BN: running statistics of channel nblk * BN + tid
+  auto epilogue = [&](const Item& it) {
+    bool tile_ok[MT];
+    unsigned voff[MT], yoff[MT];
+    item_offsets(it, voff, yoff);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) tile_ok[i] = true;
+    const unsigned rbytes = 2u * (unsigned)d * ldob, yrbytes = 2u * (unsigned)d * ldyb;   // accumulator rows are 2 lattice pixels apart
+    float s4[NG][4], q4[NG][4];
+#pragma unroll
+    for (int ng = 0; ng < NG; ++ng) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { s4[ng][k] = 0.f; q4[ng][k] = 0.f; }
+      unsigned vo[MT], yo[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) { vo[i] = voff[i] + (unsigned)(ng * 128); yo[i] = yoff[i] + (unsigned)(ng * 128); }   // 64 channels further
+      if (MODE == MODE_BNBWD) {
+        const Epi16Consts ecl = epi16_consts<MODE>(p, it.nblk * BN + ng * 64 + 4 * c16);
+        epilogue16c<MODE, MT, false>(p, acc[ng], tile_ok, vo, rbytes, yo, yrbytes, ecl, s4[ng], q4[ng]);
+      } else {
+        epilogue16c<MODE, MT, false>(p, acc[ng], tile_ok, vo, rbytes, yo, yrbytes, ec[ng], s4[ng], q4[ng]);
+      }
+    }
+    if (MODE == MODE_STATS || MODE == MODE_BNBWD) {
+      // per-workgroup statistics rows as in igemm_lattice_kernel; scratch [wave][group][4 k][2][16 c]
+      float* red = reinterpret_cast<float*>(smem + OFF_RED);
+#pragma unroll
+      for (int ng = 0; ng < NG; ++ng) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          s4[ng][k] += __shfl_xor(s4[ng][k], 16, 64); q4[ng][k] += __shfl_xor(q4[ng][k], 16, 64);
+          s4[ng][k] += __shfl_xor(s4[ng][k], 32, 64); q4[ng][k] += __shfl_xor(q4[ng][k], 32, 64);
+        }
+        if (rb == 0) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            red[(((wave * NG + ng) * 4 + k) * 2 + 0) * 16 + c16] = s4[ng][k];
+            red[(((wave * NG + ng) * 4 + k) * 2 + 1) * 16 + c16] = q4[ng][k];
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      raw_barrier();
+      if (tid < BN) {
+        const int ng2 = tid >> 6, cc = tid & 63, c2 = cc >> 2, k = cc & 3;
+        float su = 0.f, sq = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < WM; ++w2) {
+          su += red[(((w2 * NG + ng2) * 4 + k) * 2 + 0) * 16 + c2];
+          sq += red[(((w2 * NG + ng2) * 4 + k) * 2 + 1) * 16 + c2];
+        }
+        tot_su += su;                                       // tiles in the order this workgroup visits them: reproducible
+        tot_sq += sq;
+      }
+    }
+    zero_acc();
+  };
+
+  // ---- the pipeline ----------------------------------------------------------------------------------------------------
+  // flat step q = 9*chunk + tap; weights of step q live in ring stage q & 1 and are issued behind the barrier of step q - 1;
+  // the patch of a chunk is issued behind the last barrier of the previous chunk (single buffer).
+  Item cur = decode(first), nxt = cur;
+  int item = first;
+  load_consts(cur.nblk);
+  zero_acc();
+  issue_w(0, 0, 0, cur.nblk, true);
+#pragma unroll
+  for (int sl = 0; sl < PJ; ++sl) issue_slice(sl, 0, patch_base(cur, 0), patch_edges(cur, true));
+  int par = 0;                                    // parity of the flat step of this chunk's tap 0
+  bool boundary = false;                          // the previous chunk ended an item: its NST stores are the youngest VMEM operations
+  for (;;) {
+    for (int kc = 0; kc < q.nkc; ++kc) {
+      const bool last_kc = kc + 1 == q.nkc;
+      const int item_n = last_kc ? item + G : item, kc_n = last_kc ? 0 : kc + 1;
+      const bool have_n = item_n < q.items;
+      if (last_kc) nxt = have_n ? decode(item_n) : cur;
+      const unsigned pb_n = (unsigned)__builtin_amdgcn_readfirstlane((int)(last_kc ? patch_base(nxt, 0) : patch_base(cur, kc_n)));
+      const unsigned pe_n = (unsigned)__builtin_amdgcn_readfirstlane((int)(last_kc ? patch_edges(nxt, have_n) : patch_edges(cur, true)));
+      const int nblk_n = __builtin_amdgcn_readfirstlane(nxt.nblk);
+      int bb0[2], bb1[2];                         // fragment bases of the even / odd taps of this chunk
+#pragma unroll
+      for (int g = 0; g < 2; ++g) { bb0[g] = boff[g] + par * WST; bb1[g] = boff[g] + (par ^ 1) * WST; }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        // W(t) was issued one tap ago and nothing younger exists -- except, at t = 0 behind an item boundary, the epilogue stores
+        if (t == 0 && boundary) wait_vmcnt<NST>(); else wait_vmcnt<0>();
+        raw_barrier();
+        if (t < 8) issue_w((par + t + 1) & 1, t + 1, kc, cur.nblk, true);
+        else issue_w((par + 9) & 1, 0, kc_n, nblk_n, have_n);
+        if (t & 1) compute_tap(t / 3, t % 3, bb1, aoff); else compute_tap(t / 3, t % 3, bb0, aoff);
+      }
+      raw_barrier();                              // every wave has issued the MFMAs of tap 8: the patch buffer is free
+#pragma unroll
+      for (int sl = 0; sl < PJ; ++sl) issue_slice(sl, 0, pb_n, pe_n);
+      boundary = last_kc;
+      if (last_kc) epilogue(cur);
+      par ^= 1;
+    }
+    item += G;
+    if (item >= q.items) break;
+    if (nxt.nblk != cur.nblk) { load_consts(nxt.nblk); zero_acc(); }
+    cur = nxt;
+  }
+  if ((MODE == MODE_STATS || MODE == MODE_BNBWD) && tid < BN) {
+    constexpr int nrow = (MODE == MODE_BNBWD) ? 3 : 2;
+    const int nblk0 = first - (int)udiv((unsigned)first, q.mg_nblocks, (unsigned)q.nblocks) * q.nblocks;
+    const int r0 = (first - nblk0) / q.nblocks;              // this workgroup's row; its n-block never changed
+    float* col = p.stats + nblk0 * BN + tid;
+    float* row = col + (long)r0 * nrow * p.Cout;
+    row[0] = tot_su;
+    row[p.Cout] = tot_sq;
+    if (nrow == 3) row[2 * p.Cout] = 0.f;
+    for (int r = r0 + q.stat_rows; r < q.mtiles; r += q.stat_rows) {   // rows a per-tile writer would have produced: zeros
+      float* z = col + (long)r * nrow * p.Cout;
+      z[0] = 0.f;
+      z[p.Cout] = 0.f;
+      if (nrow == 3) z[2 * p.Cout] = 0.f;
+    }
+  }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 static int lattice_enabled() {
   static int v = -1;                              // UNETDC_LATTICE=0: round-1 kernels (A/B measurements)
   if (v < 0) { const char* e = getenv("UNETDC_LATTICE"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -483,6 +809,32 @@ static int launch_lattice_cfg(IgemmParams& p, const LatticeParams& q, int wgs_pe
   return check_launch("igemm_lattice_kernel");
 }
 
+template <int MODE>
+static int launch_lattice_wide_cfg(IgemmParams& p, const LatticeParams& q, hipStream_t stream) {
+  constexpr int NW = 4, BN = 128, PJ = (LPI + NW - 1) / NW;
+  constexpr int LDS = PJ * NW * 1024 + 2 * BN * 128 + NW * 2 * 128 * 4;       // 44 KB patch + 2 x 16 KB weights + 4 KB scratch = 80 KB
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_lattice_wide_kernel<MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute(igemm_lattice_wide_kernel) failed: %s", hipGetErrorString(e));
+      return UNETDC_ELAUNCH;
+    }
+    attr_done = true;
+  }
+  const long grid = lattice_grid(q.items, 2);
+  if (grid % q.nblocks != 0 || q.stat_rows != (int)(grid / q.nblocks)) {
+    set_error("igemm_lattice_wide: grid %ld / nblocks %d / stat_rows %d inconsistent", grid, q.nblocks, q.stat_rows);
+    return UNETDC_ELAUNCH;
+  }
+  hipLaunchKernelGGL((igemm_lattice_wide_kernel<MODE>), dim3((unsigned)grid), dim3(NW * 64), LDS, stream, p, q);
+  char nm[96];
+  snprintf(nm, sizeof(nm), "igemm_lattice_wide_kernel<%d>", MODE);
+  note_kernel(nm);
+  return check_launch("igemm_lattice_wide_kernel");
+}
+
 template <int WM, int WN, int MT, int NPB>
 static int launch_lattice_mode(IgemmParams& p, const LatticeParams& q, int wgs, hipStream_t stream) {
   switch (p.mode) {
@@ -511,7 +863,15 @@ int launch_igemm_lattice(IgemmParams& p, hipStream_t stream) {
   const int nimg = (int)((long)p.M / ((long)p.Ho * p.Wo));
   q.mtiles = nimg * q.tiles_per_img;              // = M / 256
   const bool wide = p.Cout % 128 == 0;
-  const int wgs = wide ? 1 : 2;                   // workgroups per CU of the two configurations
+  static int wide_wave = -1;                      // UNETDC_LAT_WIDE=0: the 8-wave 64 x 64-per-wave form for 128-channel n-blocks (A/B)
+  if (wide_wave < 0) { const char* e = getenv("UNETDC_LAT_WIDE"); wide_wave = (e && e[0] == '0') ? 0 : 1; }
+  // 4 waves x (64 pixels x 128 channels), two workgroups per CU: the statistics and folded-BatchNorm forms (the plain-store
+  // instantiation spills 36 registers -- its reloads would drain the VM counter in front of the hand-placed DMAs -- and the
+  // fused BatchNorm-backward epilogue does not fit next to 128 accumulators: both keep the 8-wave form)
+  static int wide_bnbwd = -1;                     // UNETDC_LAT_WIDE_BNBWD=0: fused BatchNorm-backward epilogue on the 8-wave form (A/B)
+  if (wide_bnbwd < 0) { const char* e = getenv("UNETDC_LAT_WIDE_BNBWD"); wide_bnbwd = (e && e[0] == '0') ? 0 : 1; }
+  const bool ww = wide && wide_wave && (p.mode == MODE_STATS || p.mode == MODE_AFFINE_RELU || (p.mode == MODE_BNBWD && wide_bnbwd));
+  const int wgs = (wide && !ww) ? 1 : 2;          // workgroups per CU of the configurations
   q.nblocks = p.Cout / (wide ? 128 : 64);
   q.items = q.mtiles * q.nblocks;
   // statistics: one row per workgroup and n-block (the kernel zero-fills the rest of the M / 256 rows).  The grid is
@@ -521,6 +881,11 @@ int launch_igemm_lattice(IgemmParams& p, hipStream_t stream) {
   q.mg_nblocks = magic(q.nblocks); q.mg_tpi = magic(q.tiles_per_img); q.mg_tpp = magic(q.tiles_x * q.tiles_y);
   q.mg_d = magic(q.d); q.mg_tx = magic(q.tiles_x);
   p.nblocks = q.nblocks;
+  if (ww) {
+    if (p.mode == MODE_STATS) return launch_lattice_wide_cfg<MODE_STATS>(p, q, stream);
+    if (p.mode == MODE_BNBWD) return launch_lattice_wide_cfg<MODE_BNBWD>(p, q, stream);
+    return launch_lattice_wide_cfg<MODE_AFFINE_RELU>(p, q, stream);
+  }
   if (wide) return launch_lattice_mode<4, 2, 4, 2>(p, q, 1, stream);
   return launch_lattice_mode<4, 1, 4, 1>(p, q, 2, stream);
 }
