@@ -21,6 +21,8 @@ SWITCH_SETS = {
     # round-2 kernels off: halo-patch / per-tap convolutions instead of the persistent lattice kernel, quadrant ring and
     # per-tap weight gradients instead of the tap-split ring and the valid-rectangle kernel, per-pixel first-layer wgrad
     "round1_kernels": {"UNETDC_LATTICE": "0", "UNETDC_WGRAD_SPLIT": "0", "UNETDC_WGRAD_RECT": "0", "UNETDC_FIRST_ROWS": "0"},
+    # the first lattice form (8 waves of 64 x 64, two patch buffers, 3-stage ring) instead of the wide-wave one
+    "lattice_8_waves": {"UNETDC_LAT_WIDE": "0"},
 }
 
 
@@ -28,8 +30,10 @@ SWITCH_SETS = {
 def test_operator_parity_under_switches(name):
     env = dict(os.environ, **SWITCH_SETS[name])
     sel = "conv3x3_fwd_dgrad_wgrad or wgrad_tap_fused or first_conv or conv_transpose or fused_bn_backward_statistics"
-    if name == "fused_without_ring_unfused_epilogues":
+    if name in ("fused_without_ring_unfused_epilogues", "lattice_8_waves"):
         sel = "wgrad_tap_fused or conv3x3_fwd_dgrad_wgrad"
+    if name == "lattice_8_waves":
+        sel = "conv3x3_fwd_dgrad_wgrad or fused_bn_backward_statistics"
     cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_ops.py"), "-m", "gpu", "-x", "-q",
            "-k", sel, "-p", "no:cacheprovider"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
