@@ -428,8 +428,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
 
 // ------------------------------------------------------------------------------------------------------------------------
 // Wide-wave form: 4 waves, each owns 64 pixels x 128 channels (two 64-channel groups: 4 M tiles x 8 N tiles).
-// SQ counters of the 64 x 64 wave tile: 0.5 ds_read_b128 per MFMA = 128 B/clk/CU with all four SIMDs busy, i.e. the LDS peak
-// before any DMA write.  Here a wave reads 4 A + 8 B fragments for 32 MFMAs (0.375 per MFMA) and the patch is shared by
+// SQ counters of the 64 x 64 wave tile: 0.5 ds_read_b128 per MFMA = 128 B/clk/CU with all four SIMDs busy, half of what the
+// LDS array delivers, and the LDS-DMA writes share the array.  Here a wave reads 4 A + 8 B fragments for 32 MFMAs (0.375 per MFMA) and the patch is shared by
 // 128 output channels.  To keep TWO workgroups per CU (4 waves each; the single patch buffer leaves the next chunk's
 // patch exposed, the other workgroup covers it) the weight ring has two 16 KB stages: 44 KB patch + 32 KB + 4 KB scratch
 // = 80 KB.  With two stages the weights of tap t+1 are issued behind the barrier of tap t (one tap = 64 MFMAs per wave
