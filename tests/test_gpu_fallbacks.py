@@ -42,8 +42,9 @@ def test_operator_parity_under_switches(name):
 
 
 def test_train_step_under_unfused_switches_matches_default():
-    """One bf16 training step at a small size: gradients with every fusion switched off == the default path
-    within bf16 rounding (same kernels' math, different launch structure)."""
+    """One bf16 training step at a small size: gradients with every fusion switched off, and with the opt-in split of the
+    pooled stages' BatchNorm-backward sums (UNETDC_FUSE_POOL_SKIP=1), == the default path within bf16 rounding (same
+    kernels' math, different launch structure)."""
     code = r'''
 import sys, torch
 sys.path.insert(0, %r)
@@ -57,16 +58,17 @@ focal_dice_loss(m(x), t, alpha=1.0, gamma=2.0, ratio=0.3).backward()
 torch.save({k: p.grad.cpu() for k, p in m.named_parameters()}, sys.argv[1])
 ''' % ROOT
     outs = []
-    for i, extra in enumerate(({}, SWITCH_SETS["fused_without_ring_unfused_epilogues"])):
+    for i, extra in enumerate(({}, SWITCH_SETS["fused_without_ring_unfused_epilogues"], {"UNETDC_FUSE_POOL_SKIP": "1"})):
         path = os.path.join("/tmp", f"unetdc_fallback_grads_{os.getpid()}_{i}.pt")
         r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **extra), cwd=ROOT,
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
         outs.append(torch.load(path, weights_only=True))
         os.remove(path)
-    for k in outs[0]:
-        a, b = outs[0][k].double(), outs[1][k].double()
-        if k.endswith(".0.bias") or k.endswith(".3.bias"):
-            continue                                            # structural zeros in front of train-mode BatchNorm
-        cos = float((a * b).sum() / (a.norm() * b.norm()).clamp_min(1e-30))
-        assert cos > 0.98, (k, cos)          # bf16 storage rounding makes the step chaotic at the 1e-2 level (DESIGN.md section 2)
+    for other in outs[1:]:
+        for k in outs[0]:
+            a, b = outs[0][k].double(), other[k].double()
+            if k.endswith(".0.bias") or k.endswith(".3.bias"):
+                continue                                        # structural zeros in front of train-mode BatchNorm
+            cos = float((a * b).sum() / (a.norm() * b.norm()).clamp_min(1e-30))
+            assert cos > 0.98, (k, cos)      # bf16 storage rounding makes the step chaotic at the 1e-2 level (DESIGN.md section 2)

@@ -278,7 +278,11 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdParams p) {
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ parts, int nparts,
+// Two sources of partial sums: A = [nA][3][csA] rows of which columns c0A .. c0A + C - 1 belong to this stage (csA = C,
+// c0A = 0 for the stage's own partial buffer; csA = 2C, c0A = C when the sums rode in the epilogue of the kernel that wrote
+// the [pixels, 2C] concat gradient), B = [nB][3][C] (optional second producer: the pooled part of an encoder stage).
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ parts, int nparts, int cs, int c0,
+                                                              const float* __restrict__ parts2, int nparts2,
                                                               double count, const float* __restrict__ gamma,
                                                               const float* __restrict__ rstd, float* dgamma,
                                                               float* dbeta, float* dbias, float* k1, float* k2,
@@ -287,9 +291,14 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   if (c >= C) return;
   double s1 = 0.0, s2 = 0.0, s3 = 0.0;
   for (int i = l; i < nparts; i += 32) {
-    s1 += (double)parts[((long)i * 3 + 0) * C + c];
-    s2 += (double)parts[((long)i * 3 + 1) * C + c];
-    s3 += (double)parts[((long)i * 3 + 2) * C + c];
+    s1 += (double)parts[((long)i * 3 + 0) * cs + c0 + c];
+    s2 += (double)parts[((long)i * 3 + 1) * cs + c0 + c];
+    s3 += (double)parts[((long)i * 3 + 2) * cs + c0 + c];
+  }
+  for (int i = l; i < nparts2; i += 32) {
+    s1 += (double)parts2[((long)i * 3 + 0) * C + c];
+    s2 += (double)parts2[((long)i * 3 + 1) * C + c];
+    s3 += (double)parts2[((long)i * 3 + 2) * C + c];
   }
   s1 = lane32_sum(s1);
   s2 = lane32_sum(s2);
@@ -737,14 +746,70 @@ int launch_bn_bwd(BnBwdParams& p, const float* gamma, float* dgamma, float* dbet
     rc = reduce_parts(parts, nb, 3 * p.C, &rp, &rows, stream, 512);
   }
   if (rc != UNETDC_OK) return rc;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 7) / 8), dim3(256), 0, stream, rp, rows,
-                     (double)p.N * p.H * p.W, gamma, p.rstd, dgamma, dbeta, dbias, k, k + p.C, k + 2 * p.C, p.C);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 7) / 8), dim3(256), 0, stream, rp, rows, p.C, 0,
+                     (const float*)nullptr, 0, (double)p.N * p.H * p.W, gamma, p.rstd, dgamma, dbeta, dbias, k, k + p.C,
+                     k + 2 * p.C, p.C);
   rc = check_launch("bn_bwd_finalize_kernel");
   if (rc != UNETDC_OK) return rc;
   const long items = Q * cpp;
   const dim3 grid2(grid_for(items, 256) > 4096 ? 4096 : grid_for(items, 256), (cpp + seg - 1) / seg);
   if (dtype == UNETDC_BF16) launch_bn_bwd_k<bf16_t>(p, pool, true, grid2, stream);
   else launch_bn_bwd_k<float>(p, pool, true, grid2, stream);
+  return check_launch("bn_bwd_kernel(apply)");
+}
+
+// Pooled encoder stage whose gradient is  dskip + scatter(dpool):  the sums are linear in the gradient, so the dskip part
+// comes in as partial rows from the epilogue of the kernel that wrote dskip (skip_parts: [skip_rows][3][skip_cs], this
+// stage's columns from skip_c0) and only the dpool part (plus S3 = sum xhat) is reduced here, from y and dpool alone:
+// the reduction pass no longer reads dskip.  Then finalize over both row sets and the usual apply pass.
+int launch_bn_bwd_pool_split(BnBwdParams& p, const float* gamma, float* dgamma, float* dbeta, float* dbias, void* workspace,
+                             long workspace_bytes, const float* skip_parts, int skip_rows, int skip_cs, int skip_c0, int dtype,
+                             hipStream_t stream) {
+  const int epc = dtype == UNETDC_BF16 ? 8 : 4;
+  UNETDC_REQUIRE(dtype == UNETDC_F32 || dtype == UNETDC_BF16, "bn_bwd_pool_split: bad dtype %d", dtype);
+  UNETDC_REQUIRE(p.y && p.dy && p.dskip && p.dpool, "bn_bwd_pool_split: null tensor");
+  UNETDC_REQUIRE(p.scale && p.shift && p.mean && p.rstd && gamma && dgamma && dbeta && workspace && skip_parts,
+                 "bn_bwd_pool_split: null pointer");
+  UNETDC_REQUIRE(p.C % epc == 0 && p.ldy % epc == 0 && p.lddy % epc == 0 && p.lds % epc == 0 && p.ldp % epc == 0,
+                 "bn_bwd_pool_split: C/ld not chunk aligned");
+  UNETDC_REQUIRE(p.H % 2 == 0 && p.W % 2 == 0, "bn_bwd_pool_split: pooling needs even H, W");
+  UNETDC_REQUIRE(skip_rows > 0 && skip_cs >= skip_c0 + p.C && skip_c0 >= 0, "bn_bwd_pool_split: bad partial-row geometry");
+  const int cpp = p.C / epc;
+  const int seg = cpp < 256 ? cpp : 256;
+  UNETDC_REQUIRE(256 % seg == 0, "bn_bwd_pool_split: C=%d unsupported", p.C);
+  const long Q = (long)p.N * (p.H / 2) * (p.W / 2);
+  const int nb = bn_bwd_blocks(Q, cpp);
+  const long need = ((long)(nb + 64) * 3 * p.C + 3 * p.C) * 4;
+  if (need > workspace_bytes) {
+    set_error("bn_bwd_pool_split: workspace too small (%ld < %ld bytes)", workspace_bytes, need);
+    return UNETDC_EWORKSPACE;
+  }
+  float* ws = reinterpret_cast<float*>(workspace);
+  float* k = ws;
+  float* parts = ws + 3 * p.C;
+  p.parts = parts;
+  p.k1 = k; p.k2 = k + p.C; p.k3 = k + 2 * p.C;
+  const dim3 grid(nb, (cpp + seg - 1) / seg);
+  BnBwdParams pr = p;
+  pr.dskip = nullptr;                                    // pooled part only: g = scatter(dpool)
+  if (dtype == UNETDC_BF16) launch_bn_bwd_k<bf16_t>(pr, true, false, grid, stream);
+  else launch_bn_bwd_k<float>(pr, true, false, grid, stream);
+  int rc = check_launch("bn_bwd_kernel(reduce, pooled part)");
+  if (rc != UNETDC_OK) return rc;
+  const float* rp; int rows;
+  rc = reduce_parts(parts, nb, 3 * p.C, &rp, &rows, stream, 512);
+  if (rc != UNETDC_OK) return rc;
+  const float* sp; int srows;
+  rc = reduce_parts(skip_parts, skip_rows, 3 * skip_cs, &sp, &srows, stream, 512);    // > 512 rows: one stage into the 64 spare rows
+  if (rc != UNETDC_OK) return rc;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 7) / 8), dim3(256), 0, stream, sp, srows, skip_cs, skip_c0, rp, rows,
+                     (double)p.N * p.H * p.W, gamma, p.rstd, dgamma, dbeta, dbias, k, k + p.C, k + 2 * p.C, p.C);
+  rc = check_launch("bn_bwd_finalize_kernel");
+  if (rc != UNETDC_OK) return rc;
+  const long items = Q * cpp;
+  const dim3 grid2(grid_for(items, 256) > 4096 ? 4096 : grid_for(items, 256), (cpp + seg - 1) / seg);
+  if (dtype == UNETDC_BF16) launch_bn_bwd_k<bf16_t>(p, true, true, grid2, stream);
+  else launch_bn_bwd_k<float>(p, true, true, grid2, stream);
   return check_launch("bn_bwd_kernel(apply)");
 }
 
@@ -897,13 +962,19 @@ __global__ __launch_bounds__(256) void stats_colsum_finalize_kernel(const float*
   if (c < C && l == 0) out[c] = (float)s;
 }
 
-int launch_stats_colsum(const float* parts, int nparts, int ctotal, int c0, int c, float* out, hipStream_t stream) {
-  UNETDC_REQUIRE(parts && out && nparts > 0 && c0 >= 0 && c > 0 && c0 + c <= ctotal, "stats_colsum: bad arguments");
+// row_floats = floats per partial row (2 * ctotal for statistics rows, 3 * ctotal for BatchNorm-backward rows)
+int launch_stats_colsum_rows(const float* parts, int nparts, int row_floats, int c0, int c, float* out, hipStream_t stream) {
+  UNETDC_REQUIRE(parts && out && nparts > 0 && c0 >= 0 && c > 0 && c0 + c <= row_floats, "stats_colsum: bad arguments");
   const float* rp; int rows;
-  int rc = reduce_parts(parts, nparts, 2 * ctotal, &rp, &rows, stream, 512);
+  int rc = reduce_parts(parts, nparts, row_floats, &rp, &rows, stream, 512);
   if (rc != UNETDC_OK) return rc;
-  hipLaunchKernelGGL(stats_colsum_finalize_kernel, dim3((c + 7) / 8), dim3(256), 0, stream, rp, rows, 2 * ctotal, c0, out, c);
+  hipLaunchKernelGGL(stats_colsum_finalize_kernel, dim3((c + 7) / 8), dim3(256), 0, stream, rp, rows, row_floats, c0, out, c);
   return check_launch("stats_colsum_finalize_kernel");
+}
+
+int launch_stats_colsum(const float* parts, int nparts, int ctotal, int c0, int c, float* out, hipStream_t stream) {
+  UNETDC_REQUIRE(c0 + c <= ctotal, "stats_colsum: bad column range");
+  return launch_stats_colsum_rows(parts, nparts, 2 * ctotal, c0, c, out, stream);
 }
 
 int launch_pack_many(const void* table_dev, int n, long total_tiles, int dtype, hipStream_t stream) {

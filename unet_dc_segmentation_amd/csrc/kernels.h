@@ -109,6 +109,10 @@ int launch_apply(ApplyParams& p, int dtype, hipStream_t stream);
 long bn_bwd_workspace_bytes(int N, int H, int W, int C, int pooled, int dtype);
 int launch_bn_bwd(BnBwdParams& p, const float* gamma, float* dgamma, float* dbeta, float* dbias, void* workspace,
                   long workspace_bytes, const float* pre_parts, int pre_nparts, int dtype, hipStream_t stream);
+int launch_bn_bwd_pool_split(BnBwdParams& p, const float* gamma, float* dgamma, float* dbeta, float* dbias, void* workspace,
+                             long workspace_bytes, const float* skip_parts, int skip_rows, int skip_cs, int skip_c0, int dtype,
+                             hipStream_t stream);
+int launch_stats_colsum_rows(const float* parts, int nparts, int row_floats, int c0, int c, float* out, hipStream_t stream);
 int launch_bn_bwd_reduce_only(BnBwdParams& p, float* parts, long parts_floats, int* nparts, int dtype,
                               hipStream_t stream);
 long head_bwd_workspace_bytes(int N, int H, int W, int C, int OC, int dtype);

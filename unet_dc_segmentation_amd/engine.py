@@ -32,6 +32,13 @@ ENCODER = ("enc1", "enc2", "enc3", "enc4")
 FUSE_BN_BWD = os.environ.get("UNETDC_FUSE_BNBWD", "1") != "0"
 # ConvTranspose2d bias gradient = column sums of the concat gradient, produced by the dgrad epilogue that writes it
 FUSE_COLSUM = os.environ.get("UNETDC_FUSE_COLSUM", "1") != "0"
+# Pooled encoder stages (gradient = skip half of the concat gradient + scatter of the pooled gradient): the skip part of their
+# BatchNorm-backward sums rides in the epilogue of the decoder dgrad that writes the concat gradient (unetdc_conv3x3_dgrad_bnstats
+# with per-column constants that are neutral for the up-sampled half), so the stage's own reduction pass reads only y and
+# dpool (unetdc_bn_relu_bwd_pool_split).  Opt-in (UNETDC_FUSE_POOL_SKIP=1): measured on MI355X the BatchNorm passes get
+# 0.08 ms cheaper per step and the four decoder dgrads 0.06 + 0.03 ms dearer (their epilogue now also reads the encoder's
+# saved outputs): no net gain, so the default keeps the two-pass form over dskip + dpool.
+FUSE_POOL_SKIP = os.environ.get("UNETDC_FUSE_POOL_SKIP", "0") == "1" and FUSE_COLSUM and FUSE_BN_BWD
 # Opt-in (UNETDC_SIDE_WGRAD=1): run the weight-gradient kernels, which hang off the backward critical
 # chain, on a side HIP stream.  Measured +0.6 % on MI355X (the MFMA kernels fill the CUs' LDS, so little
 # co-residency with the HBM-bound BatchNorm passes); off by default because overlapping kernels make
@@ -126,6 +133,21 @@ class UNetEngine:
             name = f"dec{lvl}"
             self.stages[(name, 0)] = _Stage(self, name, 0, 2 * c, c, d[name], self.npix[lvl - 1], self.res[lvl - 1])
             self.stages[(name, 3)] = _Stage(self, name, 3, c, c, d[name], self.npix[lvl - 1], self.res[lvl - 1])
+        # pooled encoder stages: per level the four per-channel constant arrays of the stage are the SECOND halves of
+        # [2C] arrays whose first halves are neutral (scale 0, shift 1, mean 0, rstd 0); the saved conv output has one spare
+        # pixel row in front (the fused epilogue addresses column C + c of the concat gradient as y[pixel][c] through a
+        # base pointer C elements early; the up-sampled half then reads the previous pixel's row: any finite value will do)
+        self.combo = {}
+        for l, name in enumerate(ENCODER):
+            st = self.stages[(name, 3)]
+            c = st.cout
+            combo = torch.zeros(4, 2 * c, device=dev, dtype=torch.float32)
+            combo[1, :c] = 1.0
+            st.scale, st.shift, st.mean, st.rstd = combo[0, c:], combo[1, c:], combo[2, c:], combo[3, c:]
+            ybuf = torch.zeros((st.npix + 1) * c, device=dev, dtype=dt)
+            st.y = ybuf[c:].view(st.npix, c)
+            st.skip_parts, st.skip_rows = None, 0
+            self.combo[l + 1] = combo
         # activations
         self.a0 = {}      # activated output of stage 0 of each block
         self.a3 = {}      # activated output of stage 3 for bottleneck / decoder blocks
@@ -391,7 +413,7 @@ class UNetEngine:
                 prev.mean.data_ptr(), prev.rstd.data_ptr(), prev.bwd_parts.data_ptr(), prev.bwd_parts.numel(),
                 __import__("ctypes").byref(self._np))
 
-    def _stage_bwd(self, st, flat, lvl, dskip, dpool, dx_out, fuse_prev=None, colsum=None):
+    def _stage_bwd(self, st, flat, lvl, dskip, dpool, dx_out, fuse_prev=None, colsum=None, skip_for=None):
         """Backward of one stage.  dskip/dpool: incoming gradient(s) of the activation;
         dx_out: [npix, cin] view to receive the input gradient (None for the first stage);
         fuse_prev: the stage consuming dx_out as its activation gradient -- its BatchNorm-backward
@@ -404,13 +426,29 @@ class UNetEngine:
         dy = st.dy
         ws, wsb = self.workspace.data_ptr(), self.ws_bytes
         pre = (st.bwd_parts.data_ptr(), st.bwd_nparts) if (st.bwd_nparts and dpool is None) else (None, 0)
+        if dpool is not None and dskip is not None and getattr(st, "skip_rows", 0):
+            # the skip part of the sums came out of the decoder dgrad that wrote dskip (see FUSE_POOL_SKIP)
+            call("unetdc_bn_relu_bwd_pool_split", dskip.data_ptr(), dskip.stride(0), dpool.data_ptr(), dpool.stride(0),
+                 st.y.data_ptr(), st.y.stride(0), st.scale.data_ptr(), st.shift.data_ptr(), st.mean.data_ptr(),
+                 st.rstd.data_ptr(), st.bn.weight.data_ptr(), dy.data_ptr(), dy.stride(0),
+                 self._gview(flat, st.bn.weight).data_ptr(), self._gview(flat, st.bn.bias).data_ptr(),
+                 self._gview(flat, st.conv.bias).data_ptr(), ws, wsb, st.skip_parts.data_ptr(), st.skip_rows,
+                 2 * st.cout, st.cout, N, h, w, st.cout, self.dt, s)
+            st.skip_rows = 0
+        else:
+            self._bn_relu_bwd_plain(st, flat, dskip, dpool, dy, pre, ws, wsb, N, h, w, s)
+        st.bwd_nparts = 0
+        self._stage_bwd_rest(st, flat, lvl, dx_out, fuse_prev, colsum, skip_for, dy, ws, wsb, N, h, w, s)
+
+    def _bn_relu_bwd_plain(self, st, flat, dskip, dpool, dy, pre, ws, wsb, N, h, w, s):
         call("unetdc_bn_relu_bwd", _ptr(dskip), dskip.stride(0) if dskip is not None else 0,
              _ptr(dpool), dpool.stride(0) if dpool is not None else 0, st.y.data_ptr(), st.y.stride(0),
              st.scale.data_ptr(), st.shift.data_ptr(), st.mean.data_ptr(), st.rstd.data_ptr(),
              st.bn.weight.data_ptr(), dy.data_ptr(), dy.stride(0), self._gview(flat, st.bn.weight).data_ptr(),
              self._gview(flat, st.bn.bias).data_ptr(), self._gview(flat, st.conv.bias).data_ptr(), ws, wsb,
              pre[0], pre[1], N, h, w, st.cout, self.dt, s)
-        st.bwd_nparts = 0
+
+    def _stage_bwd_rest(self, st, flat, lvl, dx_out, fuse_prev, colsum, skip_for, dy, ws, wsb, N, h, w, s):
         dw = self._gview(flat, st.conv.weight)
         xin = st.x_in
         with self._side_after_main() as (s2, ws2):
@@ -426,6 +464,24 @@ class UNetEngine:
                      dx_out.data_ptr(), dx_out.stride(0), *self._bnstats_args(fuse_prev), N, h, w, st.cin, st.cout,
                      st.dil, self.dt, s)
                 fuse_prev.bwd_nparts = self._np.value
+            elif dx_out is not None and colsum is not None and skip_for is not None and FUSE_POOL_SKIP:
+                # dx_out = gradient of cat([up, skip]): one epilogue gives the column sums of its first half (the up-conv
+                # bias gradient) AND the skip part of the encoder stage's BatchNorm-backward sums
+                enc, combo = skip_for
+                c = enc.cout
+                if enc.skip_parts is None:
+                    rows = _lib.load().unetdc_conv3x3_stats_rows(st.npix, 2 * c)
+                    enc.skip_parts = torch.empty((rows + 64) * 3 * 2 * c, device=self.device, dtype=torch.float32)
+                self._np = getattr(self, "_np", None) or __import__("ctypes").c_int(0)
+                es = 2 if self.dt == _lib.BF16 else 4
+                call("unetdc_conv3x3_dgrad_bnstats", dy.data_ptr(), dy.stride(0), st.w_dgrad.data_ptr(),
+                     dx_out.data_ptr(), dx_out.stride(0), enc.y.data_ptr() - c * es, c, combo[0].data_ptr(),
+                     combo[1].data_ptr(), combo[2].data_ptr(), combo[3].data_ptr(), enc.skip_parts.data_ptr(),
+                     enc.skip_parts.numel(), __import__("ctypes").byref(self._np), N, h, w, st.cin, st.cout, st.dil,
+                     self.dt, s)
+                enc.skip_rows = self._np.value
+                call("unetdc_parts_colsum", enc.skip_parts.data_ptr(), enc.skip_rows, 3 * 2 * c, colsum[1], colsum[2],
+                     colsum[0].data_ptr(), s)
             elif dx_out is not None and colsum is not None and FUSE_COLSUM:
                 call("unetdc_conv3x3_dgrad_colsum", dy.data_ptr(), dy.stride(0), st.w_dgrad.data_ptr(), dx_out.data_ptr(),
                      dx_out.stride(0), colsum[0].data_ptr(), colsum[1], colsum[2], ws, wsb, N, h, w, st.cin, st.cout,
@@ -434,11 +490,11 @@ class UNetEngine:
                 call("unetdc_conv3x3_dgrad", dy.data_ptr(), dy.stride(0), st.w_dgrad.data_ptr(), dx_out.data_ptr(),
                      dx_out.stride(0), N, h, w, st.cin, st.cout, st.dil, self.dt, s)
 
-    def _block_bwd(self, name, flat, lvl, dskip, dpool, dx_out, colsum=None):
+    def _block_bwd(self, name, flat, lvl, dskip, dpool, dx_out, colsum=None, skip_for=None):
         """stage 3 then stage 0 of a block; the gradient between them lives in the 'da' buffer."""
         da = self.grad_bufs[("da", lvl)]
         self._stage_bwd(self.stages[(name, 3)], flat, lvl, dskip, dpool, da, fuse_prev=self.stages[(name, 0)])
-        self._stage_bwd(self.stages[(name, 0)], flat, lvl, da, None, dx_out, colsum=colsum)
+        self._stage_bwd(self.stages[(name, 0)], flat, lvl, da, None, dx_out, colsum=colsum, skip_for=skip_for)
         self._notify(flat, name)
 
     def _notify(self, flat, name):
@@ -483,7 +539,8 @@ class UNetEngine:
             c = u["cout"]
             dcat = g[("dcat", lvl)]
             # the dgrad that writes dcat = grad of cat([up, enc]) also sums its first half per channel = upconv bias grad
-            self._block_bwd(f"dec{lvl}", flat, l, dact, None, dcat, colsum=(self._gview(flat, u["mod"].bias), 0, c))
+            self._block_bwd(f"dec{lvl}", flat, l, dact, None, dcat, colsum=(self._gview(flat, u["mod"].bias), 0, c),
+                            skip_for=(self.stages[(ENCODER[l], 3)], self.combo[lvl]))
             dup = dcat[:, :c]
             h, w = self.res[lvl]
             xin = u["x_in"]
