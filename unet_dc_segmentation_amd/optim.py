@@ -44,10 +44,13 @@ class FusedAdam(torch.optim.Optimizer):
         self._m = torch.zeros(n, device=dev, dtype=torch.float32)
         self._v = torch.zeros(n, device=dev, dtype=torch.float32)
         self._offs, o = [], 0
+        # ONE step counter object shared by every parameter's state entry (torch.optim.Adam keeps one per parameter, all
+        # equal): 82 separate `step += 1` on 0-dim CPU tensors cost ~0.8 ms of host time per training step
+        self._step_t = torch.tensor(float(self._step))
         for p in params:
             self._offs.append(o)
             st = self.state[p]
-            st["step"] = torch.tensor(float(self._step))
+            st["step"] = self._step_t
             st["exp_avg"] = self._m[o:o + p.numel()].view_as(p)
             st["exp_avg_sq"] = self._v[o:o + p.numel()].view_as(p)
             o += p.numel()
@@ -124,8 +127,7 @@ class FusedAdam(torch.optim.Optimizer):
                   float(b2), float(eps), self._step, self.grad_scale, dt, torch.cuda.current_stream().cuda_stream)
         if eng is not None:
             eng.weights_fresh()                   # both packed images were just rewritten from the new parameters
-        for p in params:
-            self.state[p]["step"] += 1
+        self._step_t += 1
         return loss
 
     def _step_torch(self, params, lr, b1, b2, eps):
@@ -137,4 +139,4 @@ class FusedAdam(torch.optim.Optimizer):
             st["exp_avg_sq"].mul_(b2).addcmul_(g, g, value=1.0 - b2)
             denom = (st["exp_avg_sq"].sqrt() / (bc2 ** 0.5)).add_(eps)
             p.addcdiv_(st["exp_avg"], denom, value=-lr / bc1)
-            st["step"] += 1
+        self._step_t += 1
