@@ -84,6 +84,10 @@ def test_conv3x3_fwd_dgrad_wgrad(dtype, case):
     sta = st.cpu()[: rows * 2 * cout].reshape(rows, 2, cout)
     assert torch.equal(sta[live:], torch.zeros_like(sta[live:]))
     assert torch.equal(sta[:live].double().sum(0), stc)
+    # run-to-run: same output and same partial rows, bit for bit (fixed tile order per workgroup, fixed reduction trees)
+    yv2 = G.empty_nhwc(n * h * w, cout, dtype, ld=2 * cout, off=cout)
+    st2, _ = G.conv3x3_fwd(xv, wf, bd, n, h, w, cin, cout, d, dtype, yv2, stats=True)
+    assert torch.equal(yv, yv2) and torch.equal(st[: rows * 2 * cout], st2[: rows * 2 * cout])
     # eval-mode epilogue: relu(acc*scale + shift)
     sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
     y2v = G.empty_nhwc(n * h * w, cout, dtype)
