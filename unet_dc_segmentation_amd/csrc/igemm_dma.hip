@@ -378,7 +378,17 @@ int launch_igemm_dma(IgemmParams& p, int dtype, hipStream_t stream) {
   const bool use_a = (force == 1) || (force == 0 && p.Cout % 256 == 0 && p.M >= 256 * 64 && blocks_a >= 200);
   const bool use_b = (force == 2) || (force == 0 && !use_a && p.Cout % 128 == 0);
   if (igemm_dma16_supported(p, dtype)) {               // bf16: 16x16x32 MFMA shape (igemm_dma16.hip)
-    const int cfg = (use_a && p.Cout % 256 == 0) ? 1 : ((use_b && p.Cout % 128 == 0) ? 2 : 3);
+    int cfg = (use_a && p.Cout % 256 == 0) ? 1 : ((use_b && p.Cout % 128 == 0) ? 2 : 3);
+    if (force == 0) {
+      // two measured refinements of the rule above (MI355X, bs 8):
+      //  * ConvTranspose2d forward with N = 4 * Cout >= 2048 on a small map (upconv4: 8192 pixels): 256 workgroups of
+      //    256 x 256 cover the chip and stage 25 % fewer bytes per MFMA: 46 -> 39 us
+      //  * 256 x 128 tiles that leave half of the CUs without a workgroup (bottleneck.0 dgrad: 128 workgroups) while
+      //    256 x 64 tiles fill the chip: 101 -> 85 us
+      const long blocks_b = (long)((p.M + 255) / 256) * (p.Cout / 128);
+      if (cfg == 2 && p.mode == MODE_SHUFFLE && p.Cout % 256 == 0 && blocks_a >= 200) cfg = 1;
+      else if (cfg == 2 && blocks_b >= 100 && blocks_b < 200) cfg = 3;
+    }
     return launch_igemm_dma16(p, cfg, stream);
   }
   if (use_a && p.Cout % 256 == 0) {
