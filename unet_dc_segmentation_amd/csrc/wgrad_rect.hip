@@ -166,7 +166,9 @@ static int rect_enabled() {
 }
 
 // plan: K unit = the smallest tap rectangle list (rounded up to 64 pixels); returns the number of units or 0
-static int rect_plan(int N, int H, int W, int d, WgradRectParams* out, int* tap_of_unit = nullptr) {
+// tiles = number of 256 x 256 channel tiles: with few tiles the K unit is halved so that units x tiles still gives every
+// CU a workgroup (512 -> 1024 channels: 8 tiles x 16 units = 128 workgroups ran on half of the chip)
+static int rect_plan(int N, int H, int W, int d, int tiles, WgradRectParams* out, int* tap_of_unit = nullptr) {
   int cnt[9], ry0[9], rx0[9], rh[9], rw[9], minc = 1 << 30;
   long total = 0;
   for (int t = 0; t < 9; ++t) {
@@ -180,7 +182,8 @@ static int rect_plan(int N, int H, int W, int d, WgradRectParams* out, int* tap_
   }
   if (total * 10 > 7L * 9 * N * H * W) return 0;        // >= 70 % of the padded pixels are live: nothing to gain
   auto magic = [](unsigned v) { return v <= 1 ? 0u : (unsigned)(((1ull << 32) + v - 1) / v); };
-  const int unit = ((minc + 63) / 64) * 64;
+  const int split = (16L * tiles < 256 && minc >= 256) ? 2 : 1;
+  const int unit = ((minc / split + 63) / 64) * 64;
   int nu = 0;
   for (int t = 0; t < 9; ++t)
     for (int b = 0; b < cnt[t]; b += unit) {
@@ -202,11 +205,12 @@ bool wgrad_rect_supported(int N, int H, int W, int CI, int CJ, int lda, int ldb,
   if (CI % 256 != 0 || CJ % 256 != 0 || d < 1) return false;
   const long P = (long)N * H * W;
   if (P * lda * 2 >= (1L << 31) || P * ldb * 2 >= (1L << 31)) return false;
-  return rect_plan(N, H, W, d, nullptr) > 0;
+  return rect_plan(N, H, W, d, (CI / 256) * (CJ / 256), nullptr) > 0;
 }
 
 long wgrad_rect_workspace_bytes(int N, int H, int W, int CI, int CJ, int d) {
-  const int nu = rect_plan(N, H, W, d, nullptr);
+  if (CI % 256 != 0 || CJ % 256 != 0) return 0;
+  const int nu = rect_plan(N, H, W, d, (CI / 256) * (CJ / 256), nullptr);
   return (long)nu * CI * CJ * 4;
 }
 
@@ -217,7 +221,7 @@ int launch_wgrad_rect(const void* dy, int lddy, const void* x, int ldx, float* o
   p.N = N; p.H = H; p.W = W; p.CI = CI; p.CJ = CJ; p.lddy = lddy; p.ldx = ldx; p.d = d;
   p.itiles = CI / 256; p.jtiles = CJ / 256;
   int utap[RECT_MAXU];
-  const int nu = rect_plan(N, H, W, d, &p, utap);
+  const int nu = rect_plan(N, H, W, d, p.itiles * p.jtiles, &p, utap);
   UNETDC_REQUIRE(nu > 0, "wgrad_rect: unsupported geometry");
   const long need = (long)nu * CI * CJ * 4;
   if (need > workspace_bytes) {
