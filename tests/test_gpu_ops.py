@@ -106,7 +106,8 @@ def test_conv3x3_fwd_dgrad_wgrad(dtype, case):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("case", [(2, 512, 256, 64, 64, 1), (1, 520, 512, 128, 64, 1), (4, 256, 256, 64, 128, 2),
-                                  (2, 128, 128, 256, 128, 8), (8, 64, 64, 128, 256, 4)])
+                                  (2, 128, 128, 256, 128, 8), (8, 64, 64, 128, 256, 4),
+                                  (5, 64, 64, 1024, 512, 1)])   # 128 channel tiles x 5 images: two images per workgroup (2 + 2 + 1)
 def test_wgrad_tap_fused(dtype, case):
     """>= 256K pixels with a 64-channel side: routed to wgrad_fused.hip (one staging for all 9 taps)."""
     n, h, w, cin, cout, d = case

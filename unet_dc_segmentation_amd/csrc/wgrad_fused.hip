@@ -31,6 +31,7 @@ struct WgradFusedParams {
   float* part;      // [units][9][CI][CJ]
   int N, H, W, CI, CJ, lddy, ldx, d;
   int ysplit, rows_per_unit, itiles, jtiles;
+  int imgs_per_unit;   // tap-split ring kernel with ysplit == 1: a workgroup walks this many images of its segment in turn
 };
 
 template <typename T> struct FusedCfg;
@@ -444,7 +445,12 @@ __device__ __forceinline__ void ring_split_body(const WgradFusedParams& p) {
   const int i0 = it * 64, j0 = jt * 64;
   const int segs = p.W / SEG;
   const int ys = unit % p.ysplit, strip = unit / p.ysplit;
-  const int n = strip / segs, x0 = (strip - n * segs) * SEG;
+  // imgs_per_unit > 1 (only with ysplit == 1): the workgroup accumulates over several images of one segment, so a layer
+  // with many channel tiles writes fewer fp32 slabs (1024 -> 512 channels at 64 x 64: 8 slabs of 18.9 MB were written and
+  // re-read by the reduce kernel, and 1024 workgroups made two rounds on the chip)
+  const int ipu = p.imgs_per_unit > 1 ? p.imgs_per_unit : 1;
+  const int n0 = (strip / segs) * ipu, x0 = (strip - (strip / segs) * segs) * SEG;
+  int n = n0;
   const int ybeg = ys * p.rows_per_unit;
   const int yend = min(ybeg + p.rows_per_unit, p.H);
   const int nsteps = yend - ybeg;
@@ -501,6 +507,9 @@ __device__ __forceinline__ void ring_split_body(const WgradFusedParams& p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[t][ih][e] = 0.f;
 
+  for (int img = 0; img < ipu && n0 + img < p.N; ++img) {
+  n = n0 + img;
+  if (img > 0) raw_barrier();                            // the previous image's last fragments have been read by every wave
   for (int rho = 0; rho < 2 * d; ++rho) issue_x(rho, ybeg - d + rho);
   int gslot_x = 2 * d, gslot_dy = 0;
 #pragma unroll
@@ -534,6 +543,7 @@ __device__ __forceinline__ void ring_split_body(const WgradFusedParams& p) {
     sl2 = (sl2 + 1 == R) ? 0 : sl2 + 1;
     sdy = (sdy + 1 == NDY) ? 0 : sdy + 1;
   }
+  }                                                      // images of this unit
 
   // ---- tap 4: tg 1's half (slot 0) joins tg 0's (slot 4) through LDS; every DMA has landed (vmcnt(0) on the last step) ----
   float* xch = reinterpret_cast<float*>(smem);
@@ -654,6 +664,14 @@ int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* 
   if (split < 0) { const char* e = getenv("UNETDC_WGRAD_SPLIT"); split = (e && e[0] == '0') ? 0 : 1; }
   if (pf && dtype == UNETDC_BF16 && split) {
     const int lds = ring_lds(d, dtype, pf);
+    long nwg = (long)units * p.itiles * p.jtiles;
+    if (p.ysplit == 1 && nwg > 512 && N > 1) {           // more than two workgroups per CU: walk several images per workgroup
+      int ipu = (int)((nwg + 511) / 512);
+      if (ipu > N) ipu = N;
+      p.imgs_per_unit = ipu;
+      *units_out = (W / fused_seg(dtype)) * ((N + ipu - 1) / ipu);
+      nwg = (long)*units_out * p.itiles * p.jtiles;
+    }
     const void* fn = pf == 2 ? reinterpret_cast<const void*>(&wgrad_ring_split_kernel<2>)
                              : reinterpret_cast<const void*>(&wgrad_ring_split_kernel<1>);
     static bool split_attr[3] = {false, false, false};
