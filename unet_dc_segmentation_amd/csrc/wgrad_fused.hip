@@ -586,6 +586,142 @@ __global__ __launch_bounds__(256, 2) void wgrad_ring_split_kernel(const WgradFus
   else ring_split_body<PF, 1>(p);
 }
 
+template <int TG>
+__device__ __forceinline__ void fused_split_body(const WgradFusedParams& p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using T = bf16_t;
+  constexpr int SEG = FusedCfg<T>::SEG;
+  constexpr int XR = SEG + 16;                         // X segment rows (x0-d .. x0+SEG-1+d, d <= 8)
+  constexpr int ES = (int)sizeof(T);
+  constexpr int RB = 64 * ES;                          // bytes per pixel row (64 channels)
+  constexpr int CPR = RB / 16, RPI = 64 / CPR;         // lanes per row, rows per DMA instruction
+  constexpr int DYI = SEG / RPI, XI = XR / RPI;        // DMA instructions: dY segment, one X segment
+  constexpr int NSLOT = (DYI + 3 * XI + 3) / 4;        // per wave
+  constexpr int DYB = SEG * RB, XB = XR * RB;
+  constexpr int STAGE = DYB + 3 * XB;
+  static_assert(SEG % RPI == 0 && XR % RPI == 0, "segment/instruction mismatch");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lds_base = lds_addr_of(smem);
+  const int qj = wave & 1;
+  constexpr int tg = TG;
+  // block -> (unit, it, jt); unit -> (image, x segment, y range)
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int tiles = p.itiles * p.jtiles;
+  const int unit = L / tiles, trem = L - unit * tiles;
+  const int it = trem / p.jtiles, jt = trem - it * p.jtiles;
+  const int i0 = it * 64, j0 = jt * 64;
+  const int segs = p.W / SEG;
+  const int ys = unit % p.ysplit, strip = unit / p.ysplit;
+  const int n = strip / segs, x0 = (strip - n * segs) * SEG;
+  const int ybeg = ys * p.rows_per_unit;
+  const int yend = min(ybeg + p.rows_per_unit, p.H);
+
+  const unsigned dybytes = (unsigned)((long)p.N * p.H * p.W * p.lddy * ES);
+  const unsigned xbytes = (unsigned)((long)p.N * p.H * p.W * p.ldx * ES);
+  const __amdgpu_buffer_rsrc_t dyr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, dybytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, xbytes, 0x00020000);
+
+  // ---- DMA slots of this wave: slot q -> global instruction index gi = wave + 4*q --------------
+  //   gi < DYI            : dY segment, instruction gi
+  //   gi = DYI + ky*XI + k: X segment ky, instruction k
+  const int sub = lane / CPR, pc = lane % CPR;
+  unsigned colb[NSLOT];          // byte offset inside the image row (pixel * ld + channel chunk) or FOOB
+#pragma unroll
+  for (int q = 0; q < NSLOT; ++q) {
+    const int gi = wave + 4 * q;
+    if (gi < DYI) {
+      const int row = gi * RPI + sub;                                  // pixel x0 + row
+      const int c = Frag<T, 1>::src_chunk(row, pc);
+      colb[q] = (unsigned)(((x0 + row) * p.lddy + i0) * ES + c * 16);
+    } else if (gi < DYI + 3 * XI) {
+      const int k = (gi - DYI) % XI;
+      const int row = k * RPI + sub;                                   // pixel x0 - d + row
+      const int gx = x0 - p.d + row;
+      const int c = Frag<T, 1>::src_chunk(row, pc);
+      colb[q] = ((unsigned)gx < (unsigned)p.W) ? (unsigned)((gx * p.ldx + j0) * ES + c * 16) : FOOB;
+    } else {
+      colb[q] = FOOB;
+    }
+  }
+
+  f32x16 acc[5][2];
+#pragma unroll
+  for (int t = 0; t < 5; ++t)
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][ih][e] = 0.f;
+
+  auto issue = [&](int stage, int y) {
+#pragma unroll
+    for (int q = 0; q < NSLOT; ++q) {
+      const int gi = wave + 4 * q;                                     // wave-uniform
+      if (gi < DYI) {
+        const unsigned rowbase = (unsigned)((long)(n * p.H + y) * p.W * p.lddy * ES);
+        lds_dma16(dyr, lds_base + stage * STAGE + gi * 1024, colb[q], rowbase);
+      } else if (gi < DYI + 3 * XI) {
+        const int ky = (gi - DYI) / XI, k = (gi - DYI) - ky * XI;
+        const int yy = y + (ky - 1) * p.d;
+        const bool yok = (unsigned)yy < (unsigned)p.H;
+        const unsigned rowbase = (unsigned)((long)(n * p.H + (yok ? yy : 0)) * p.W * p.ldx * ES);
+        const unsigned v = (yok && colb[q] != FOOB) ? colb[q] : FOOB;
+        lds_dma16(xr, lds_base + stage * STAGE + DYB + ky * XB + k * 1024, v, rowbase);
+      }
+    }
+  };
+
+  const int nsteps = yend - ybeg;
+  if (nsteps > 0) issue(0, ybeg);
+  for (int s = 0; s < nsteps; ++s) {
+    wait_vmcnt<0>();                                   // asm DMA + raw barrier: see lds_dma.h
+    raw_barrier();
+    if (s + 1 < nsteps) issue((s + 1) & 1, ybeg + s + 1);
+    const unsigned char* sdy = smem + (s & 1) * STAGE;
+    const unsigned char* sx = sdy + DYB;
+    ring_split_step<TG>(acc, sdy, sx, sx + XB, sx + 2 * XB, lane, qj, p.d);
+  }
+
+  // ---- tap 4: tg 1's half (slot 0) joins tg 0's (slot 4) through LDS (every DMA has landed: vmcnt(0) on the last step) ----
+  float* xch = reinterpret_cast<float*>(smem);
+  __syncthreads();
+  if (tg == 1) {
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) xch[((qj * 2 + ih) * 16 + reg) * 64 + lane] = acc[0][ih][reg];
+  }
+  __syncthreads();
+  if (tg == 0) {
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) acc[4][ih][reg] += xch[((qj * 2 + ih) * 16 + reg) * 64 + lane];
+  }
+  // ---- partial slab: part[unit][t][i][j];  tg 0 stores taps 0..4, tg 1 taps 5..8 ----
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int sl = 0; sl < 5; ++sl) {
+    if (tg == 1 && sl == 0) continue;
+    const int t = sl + (tg == 0 ? 0 : 4);
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih) {
+      float* slab = p.part + ((long)unit * 9 + t) * p.CI * p.CJ + (long)(i0 + ih * 32 + 4 * h) * p.CJ + j0 + qj * 32 + r;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) slab[(long)((reg & 3) + 8 * (reg >> 2)) * p.CJ] = acc[sl][ih][reg];
+    }
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+// tap-split form of the three-segment kernel (d = 4, 8): same staging, the wave roles of wgrad_ring_split_kernel
+__global__ __launch_bounds__(256, 2) void wgrad_fused_split_kernel(const WgradFusedParams p) {
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7) == 0) fused_split_body<0>(p);
+  else fused_split_body<1>(p);
+}
+
 // LDS bytes of the ring kernel, or 0 when the configuration does not leave room for two workgroups per CU
 static int ring_lds(int d, int dtype, int pf) {
   const int es = dtype == UNETDC_BF16 ? 2 : 4, seg = dtype == UNETDC_BF16 ? 64 : 32;
@@ -719,6 +855,21 @@ int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* 
   const int es = dtype == UNETDC_BF16 ? 2 : 4;
   const int seg = fused_seg(dtype);
   const int lds = 2 * (seg * 64 * es + 3 * (seg + 16) * 64 * es);
+  if (dtype == UNETDC_BF16 && split) {                   // d = 4, 8 in bf16: tap-split wave roles on the three-segment staging
+    static bool sattr = false;
+    if (!sattr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fused_split_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(wgrad_fused_split_kernel) failed: %s", hipGetErrorString(e));
+        return UNETDC_ELAUNCH;
+      }
+      sattr = true;
+    }
+    hipLaunchKernelGGL(wgrad_fused_split_kernel, dim3((unsigned)nwg), dim3(256), lds, stream, p);
+    note_kernel("wgrad_fused_split_kernel");
+    return check_launch("wgrad_fused_split_kernel");
+  }
   static bool attr_done[2] = {false, false};
   const void* fn = dtype == UNETDC_BF16 ? reinterpret_cast<const void*>(&wgrad_fused_kernel<bf16_t>)
                                         : reinterpret_cast<const void*>(&wgrad_fused_kernel<float>);
