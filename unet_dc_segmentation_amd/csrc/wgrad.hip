@@ -188,22 +188,25 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   const long q = (long)blockIdx.x * 64 + lane;             // float4 index into one slab [ntaps][n]
   const long total4 = n * ntaps / 4;
-  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a, d = a;
   if (q < total4) {
     const float4* src = reinterpret_cast<const float4*>(part) + q;
     const long stride4 = total4;
     int ks = g;
-    for (; ks + 4 < ksplit; ks += 8) {
+    for (; ks + 12 < ksplit; ks += 16) {                   // four slabs in flight per lane (fixed order: reproducible)
       const float4 u = src[(long)ks * stride4], v = src[(long)(ks + 4) * stride4];
+      const float4 w = src[(long)(ks + 8) * stride4], z = src[(long)(ks + 12) * stride4];
       a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
       b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+      c.x += w.x; c.y += w.y; c.z += w.z; c.w += w.w;
+      d.x += z.x; d.y += z.y; d.z += z.z; d.w += z.w;
     }
-    if (ks < ksplit) {
+    for (; ks < ksplit; ks += 4) {
       const float4 u = src[(long)ks * stride4];
       a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
     }
   }
-  red[g][lane] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  red[g][lane] = make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
   __syncthreads();
   if (g == 0 && q < total4) {
     float4 s = red[0][lane];
