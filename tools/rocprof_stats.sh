@@ -12,7 +12,8 @@ python3 - <<PY
 import csv
 rows=list(csv.DictReader(open("gpurun_out/${tag}_kernel_stats.csv")))
 tot=sum(float(r["TotalDurationNs"]) for r in rows)
-print(f"total kernel time {tot/1e6/7:.3f} ms/step over 7 steps, {sum(int(r['Calls']) for r in rows)/7:.0f} launches/step")
+NS = 11   # steps in the trace: 1 initialisation + 2 warm-up + 5 timed + 3 instrumented (HBM leg) steps of bench.py
+print(f"total kernel time {tot/1e6/NS:.3f} ms/step over {NS} steps, {sum(int(r['Calls']) for r in rows)/NS:.0f} launches/step")
 for r in rows[:45]:
-    print(f"{r['Name'][:95]:95s} {int(r['Calls'])/7:6.1f}/step {float(r['TotalDurationNs'])/7e3:9.1f} us/step  avg {float(r['AverageNs'])/1e3:8.1f} us")
+    print(f"{r['Name'][:95]:95s} {int(r['Calls'])/NS:6.1f}/step {float(r['TotalDurationNs'])/NS/1e3:9.1f} us/step  avg {float(r['AverageNs'])/1e3:8.1f} us")
 PY
