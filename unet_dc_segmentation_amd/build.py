@@ -28,20 +28,65 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"]
+OBJ_DIR = os.path.join(CSRC, "_obj")
+
+
+def _includes(path, seen=None):
+    """Transitive closure of the quoted #include files of one translation unit (for the per-object cache key)."""
+    import re
+    seen = set() if seen is None else seen
+    for m in re.finditer(r'^\s*#include\s+"([^"]+)"', open(path).read(), re.M):
+        q = os.path.normpath(os.path.join(os.path.dirname(path), m.group(1)))
+        if q not in seen and os.path.exists(q):
+            seen.add(q)
+            _includes(q, seen)
+    return seen
+
+
+def _object_key(src):
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for q in [src] + sorted(_includes(src)):
+        h.update(open(q, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=True):
+    """One hipcc -c per translation unit (in parallel, objects cached under csrc/_obj by a hash of the source, its
+    headers and the flags), then one link."""
     if not force and not needs_build():
         return OUT
     # -fno-slp-vectorize: keeps the channel-pair arithmetic scalar (no v_pk_*_f32).  The packed build of the
     # fused BatchNorm-backward epilogue was not run-to-run deterministic on MI355X (csrc/igemm_epilogue.h,
     # BUILD NOTE); the scalar build is, and measures the same speed.
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", "-fno-slp-vectorize", *[os.path.join(CSRC, f) for f in SOURCES], "-o", OUT]
-    if verbose:
-        print("[unetdc build]", " ".join(cmd), flush=True)
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+
+    def one(f):
+        src = os.path.join(CSRC, f)
+        obj = os.path.join(OBJ_DIR, f"{os.path.splitext(f)[0]}.{_object_key(src)}.o")
+        if force or not os.path.exists(obj):
+            for old in os.listdir(OBJ_DIR):
+                if old.startswith(os.path.splitext(f)[0] + "."):
+                    os.unlink(os.path.join(OBJ_DIR, old))
+            cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+            if verbose:
+                print("[unetdc build]", " ".join(cmd), flush=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                sys.stderr.write(r.stdout + r.stderr)
+                raise RuntimeError(f"hipcc failed on {f}")
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("hipcc failed building libunetdc_hip.so")
+        raise RuntimeError("hipcc failed linking libunetdc_hip.so")
     return OUT
 
 
