@@ -292,6 +292,97 @@ def hbm_leg(step, es, nsteps=3):
             "measured": f"HIP events around each call, {nsteps} instrumented steps after the timed region", "entries": rows}
 
 
+def synthetic_micrograph(seed, h=1040, w=1388, discs=300):
+    """A decoded RGB micrograph stand-in (uint8 [h, w, 3]): smooth background gradient + noise + bright discs."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = 40.0 + 30.0 * (yy / h) + 20.0 * (xx / w) + rng.normal(0, 6, (h, w))
+    for _ in range(discs):
+        cy, cx, r = rng.integers(0, h), rng.integers(0, w), rng.uniform(2, 18)
+        y0, y1, x0, x1 = max(int(cy - r), 0), min(int(cy + r) + 1, h), max(int(cx - r), 0), min(int(cx + r) + 1, w)
+        m = (yy[y0:y1, x0:x1] - cy) ** 2 + (xx[y0:y1, x0:x1] - cx) ** 2 <= r * r
+        img[y0:y1, x0:x1][m] += 90.0
+    g = np.clip(img, 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(np.stack([g, g, (g * 0.9).astype(np.uint8)], axis=-1))
+
+
+def quantify_bench(args, real_stdout):
+    """--mode quantify: the droplet-quantification flow of quantify_droplets_batch.py (preprocess -> forward -> threshold
+    -> resize to the original size -> connected components -> per-droplet table) on decoded 1040 x 1388 RGB arrays that
+    sit in host memory (PNG decode and the PNG/CSV writes of the script are excluded on both sides), batch 8; next to it
+    the same flow through the script's own DEVICE == "cpu" path on a bounded sample."""
+    import quantify_droplets_batch as qdb
+    from models.model_2 import UNetDC
+    from unet_dc_segmentation_amd.droplets import mask_and_droplets_batch
+    from unet_dc_segmentation_amd.preprocess import preprocess_device
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    model = UNetDC(in_channels=3, out_channels=1)
+    with torch.no_grad():
+        model.out_conv.bias.fill_(-1.2)                    # random init sits near p = 0.5: push the mask to droplet-like sparsity
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(dev).eval()
+    model.set_compute_dtype(args.dtype)
+    B, size, radius, thresh, min_area = args.batch, 512, 50, 0.3, 1
+    imgs = [synthetic_micrograph(7 + i) for i in range(B)]
+    hw = [im.shape[:2] for im in imgs]
+
+    def batch_once():
+        with torch.no_grad():
+            x = torch.stack([preprocess_device(im, radius, size, dev) for im in imgs])
+            probs = model(x)
+            res = mask_and_droplets_batch(probs[:, 0], thresh, hw, min_area)
+            tabs = [qdb._droplet_table(a, cy, cx, None) for _, a, cy, cx in res]
+            masks = [m.cpu() for m, *_ in res]             # the script writes them as PNGs
+        return tabs, masks
+
+    tabs, _ = batch_once()
+    torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        batch_once()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tabs, _ = batch_once()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    out = {"metric": "images/sec droplet quantification (preprocess + forward + mask + connected components), "
+                     "1040x1388 RGB -> 512x512x3 U-Net-DC, bs=8",
+           "value": B / dt, "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+           "data": "synthetic",
+           "config": {"workload": "quantify_droplets_batch.py flow on decoded host arrays: H2D, rolling ball r=50, bilinear "
+                                  "resize, eval forward, threshold 0.3, resize to 1040x1388, 4-connected components, "
+                                  "droplet tables + uint8 masks back on the host; PNG decode / PNG+CSV writes excluded",
+                      "global_batch": B, "parallelism": "dp1"},
+           "droplets_per_image": float(np.mean([len(t) for t in tabs]))}
+    if not args.no_cpu_baseline:
+        ncpu = 2
+        cores = host_cores()
+        torch.set_num_threads(cores)
+        from utils.data_loader import resize_image, rolling_ball_correction_rgb
+        from unet_dc_segmentation_amd.droplets import resize_mask_like_reference
+        cpu_model = UNetDC(in_channels=3, out_channels=1)
+        cpu_model.load_state_dict(sd)
+        cpu_model.eval()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            xs = []
+            for im in imgs[:ncpu]:
+                c = rolling_ball_correction_rgb(im, radius)
+                xs.append(torch.from_numpy(resize_image(c, size).astype(np.float32) / 255.0).permute(2, 0, 1))
+            pr = cpu_model(torch.stack(xs))
+            m512 = (pr[:, 0] > thresh).to(torch.uint8).numpy()
+            for i in range(ncpu):
+                qdb.quantify(resize_mask_like_reference(m512[i], hw[i][1], hw[i][0]), min_area, None)
+        ct = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": ncpu / ct, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "cpu_model": cpu_model_name(),
+                               "sample": f"{ncpu} images through the script's DEVICE == 'cpu' path (numpy restatement of the "
+                                         f"OpenCV operators, ATen-CPU fp32 forward, SciPy labelling): {ct:.1f} s"}
+    os.write(real_stdout, (json.dumps(out) + "\n").encode())
+
+
 def self_launch(args, argv):
     """--gpus N without a torchrun environment: become the launcher.  Nothing here touches HIP (device_count() reads
     sysfs on this image); the children are fresh processes, never an exec of an initialised one."""
@@ -339,8 +430,9 @@ def main():
     ap.add_argument("--adam", choices=["hip", "fused", "foreach"], default="hip",
                     help="hip = this repo's one-kernel Adam + weight re-pack (default); fused / foreach = torch.optim.Adam")
     ap.add_argument("--per-layer", action="store_true", help="print a per-call timing table to stderr (diagnostic)")
-    ap.add_argument("--mode", default="train", choices=["train", "infer"],
-                    help="train = the headline metric (default); infer = forward-only eval (BASELINE configs[1])")
+    ap.add_argument("--mode", default="train", choices=["train", "infer", "quantify"],
+                    help="train = the headline metric (default); infer = forward-only eval (BASELINE configs[1]); "
+                         "quantify = the droplet-quantification flow of quantify_droplets_batch.py (SURVEY 8 f1/f2)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))
@@ -352,6 +444,10 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    if args.mode == "quantify":
+        assert torch.cuda.is_available(), "bench.py needs a HIP device"
+        quantify_bench(args, real_stdout)
+        return
     from unet_dc_segmentation_amd import _lib, dp as dpmod
     from utils.metrics_DC import focal_dice_loss
     # RCCL ("nccl") is the production backend; UNETDC_DIST_BACKEND=gloo + UNETDC_BENCH_DEVICE=0 lets several

@@ -100,11 +100,15 @@ def run_batch(tensors, meta, model, mask_dir, overlay_dir, thresh, min_area, px_
     probs = model(batch)                                 # sigmoid probabilities (model_2.py:80)
     on_device = probs.is_cuda
     masks512 = None if on_device else (probs[:, 0] > thresh).to(torch.uint8).numpy()
+    if on_device:                                        # the whole batch enqueued back to back, ONE host wait (droplets.py)
+        from unet_dc_segmentation_amd.droplets import mask_and_droplets_batch
+        dev_out = mask_and_droplets_batch(probs[:, 0], thresh, [m[1] for m in meta], min_area)
     for i in range(len(tensors)):
         fpath, (oh, ow) = meta[i]
         name = Path(fpath).stem
         if on_device:
-            mask, df = quantify_device(probs[i, 0], thresh, (oh, ow), min_area, px_per_um)
+            mask_d, area, cy, cx = dev_out[i]
+            mask, df = mask_d.cpu().numpy(), _droplet_table(area, cy, cx, px_per_um)
         else:
             mask = resize_mask_like_reference(masks512[i], ow, oh)
             df = quantify(mask, min_area, px_per_um)

@@ -18,7 +18,22 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, q):
+def _stage_order(model):
+    """The ready ranges exactly as engine.UNetEngine.backward announces them: per conv3x3 stage (conv + BatchNorm), per
+    up-convolution, the head -- in reverse parameters() order."""
+    order = [[model.out_conv]]
+    for lvl in (1, 2, 3, 4):
+        d = getattr(model, f"dec{lvl}")
+        order += [[d[3], d[4]], [d[0], d[1]], [getattr(model, f"upconv{lvl}")]]
+    b = model.bottleneck
+    order += [[b[3], b[4]], [b[0], b[1]]]
+    for n in ("enc4", "enc3", "enc2", "enc1"):
+        e = getattr(model, n)
+        order += [[e[3], e[4]], [e[0], e[1]]]
+    return order
+
+
+def _worker(rank, world, port, q, full=True):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
         torch.set_num_threads(2)
@@ -29,7 +44,7 @@ def _worker(rank, world, port, q):
         from utils.metrics_DC import focal_dice_loss
         torch.manual_seed(100 + rank)                      # different init per rank on purpose
         model = UNetDC(1, 1)
-        dp = DataParallel(model, bucket_bytes=8 << 20)
+        dp = DataParallel(model)                            # default bucket policy: merge to >= 16 MiB, cut at 32 MiB
         # 1. replicas identical after the rank-0 broadcast
         chk = torch.stack([p.detach().double().sum() for p in model.parameters()])
         gathered = [torch.zeros_like(chk) for _ in range(world)]
@@ -43,17 +58,24 @@ def _worker(rank, world, port, q):
             o += p.numel()
         flat = torch.full((o,), float(rank + 1))
         flat[:1000] += torch.arange(1000.0) * (rank + 1)
-        order = ["out_conv", "dec1", "upconv1", "dec2", "upconv2", "dec3", "upconv3", "dec4", "upconv4",
-                 "bottleneck", "enc4", "enc3", "enc2", "enc1"]
-        for name in order:
-            ps = list(getattr(model, name).parameters())
+        for mods in _stage_order(model):
+            ps = [p for m in mods for p in m.parameters()]
             dp._on_ready(flat, offs[id(ps[0])], offs[id(ps[-1])] + ps[-1].numel())
         dp.finish()
+        # the bucket schedule DESIGN.md section 5 states (fp32 MB): head...dec4.3 | dec4.0 | upconv4 + bottleneck.3 cut in
+        # two | bottleneck.0 | enc4 + enc3 | enc2 + enc1 at finish()
+        assert [round(n * 4 / 1e6, 1) for n in dp.schedule] == [21.5, 18.9, 23.1, 23.1, 18.9, 17.7, 1.0], dp.schedule
+        assert max(dp.schedule) * 4 <= 32 << 20
         mean_scale = sum(range(1, world + 1)) / world
         expect = torch.full((o,), mean_scale)
         expect[:1000] += torch.arange(1000.0) * mean_scale
         assert torch.allclose(flat, expect, rtol=0, atol=1e-5)
-        assert 2 <= dp.stats["buckets"] <= 14 and dp.stats["elems"] == o       # every element exactly once
+        assert dp.stats["buckets"] == 7 and dp.stats["elems"] == o             # every element exactly once
+        if not full:
+            dist.barrier()
+            dist.destroy_process_group()
+            q.put((rank, "ok"))
+            return
         # 3. end-to-end step on the ATen-CPU path: averaged gradients == mean of the per-rank gradients
         xs = [recipe.seeded_input(50 + r, (1, 1, 32, 32)) for r in range(world)]
         ts = [recipe.seeded_target(60 + r, (1, 1, 32, 32)) for r in range(world)]
@@ -87,6 +109,23 @@ def test_data_parallel_world2_gloo():
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=500) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert all(r[1] == "ok" for r in results), results
+
+
+@pytest.mark.timeout(600)
+def test_data_parallel_world4_gloo_bucket_schedule():
+    """Four ranks: coalesced replica broadcast, the per-stage ready ranges and the 16 / 32 MiB bucket policy; every
+    element averaged exactly once."""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, False)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=500) for _ in range(world)]

@@ -228,6 +228,32 @@ def test_fused_adam_cpu_formulas_match_torch():
     sda, sdb = oa.state_dict(), ob.state_dict()
     assert sda["state"].keys() == sdb["state"].keys() and set(sda["state"][0]) == set(sdb["state"][0])
     assert torch.allclose(sda["state"][0]["exp_avg"], sdb["state"][0]["exp_avg"], rtol=1e-6, atol=1e-10)
+    # the round trip INTO torch.optim.Adam must also STEP correctly: full default set in the group (torch's step reads
+    # weight_decay / amsgrad / maximize / ...), and one `step` tensor per parameter (a shared one would be advanced once
+    # per parameter by the non-fused torch implementation and spoil the bias corrections)
+    assert sda["param_groups"][0].keys() == sdb["param_groups"][0].keys()
+    steps = [st["step"] for st in sda["state"].values()]
+    assert len({id(t) for t in steps}) == len(steps) and all(float(t) == 3.0 for t in steps)
+    oc = torch.optim.Adam(a.parameters(), lr=1e-2, foreach=False)
+    oc.load_state_dict(sda)
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        pa.grad = torch.randn(pa.shape, generator=g)
+        pb.grad = pa.grad.clone()
+    oc.step()                                               # torch Adam continues a's optimisation from FusedAdam's state
+    ob.step()
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-6, atol=1e-8)
+    assert all(float(st["step"]) == 4.0 for st in oc.state.values())
+    # ... and back: FusedAdam picks up torch.optim.Adam's state
+    od = FusedAdam(a, lr=1e-2)
+    od.load_state_dict(ob.state_dict())
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        pa.grad = torch.randn(pa.shape, generator=g)
+        pb.grad = pa.grad.clone()
+    od.step()
+    ob.step()
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-6, atol=1e-8)
 
 
 def test_nearest_resize_restates_cv2_rule():

@@ -7,8 +7,12 @@ counted and must not differ by more than the measured kernel error).  Gradients 
 an fp64 evaluation with a tolerance tied to the fp32 reference's own rounding error, because
 BatchNorm over 8 samples at the 2x2 bottleneck of the 32x32 goldens is ill-conditioned (the fp32
 reference itself is 4e-3..9e-3 away from fp64 there, see tests/test_oracle_golden.py).
-bf16 path -- throughput configuration: probabilities within 3e-2, loss within 2e-2 relative,
-gradient direction cosine >= 0.98 per large tensor.
+bf16 path -- throughput configuration: probabilities within 3e-2 of the fp32 reference and 2e-2 of the bf16-STORAGE
+emulation of the reference (oracle/unetdc_torch_cpu.py, emulate_bf16=True), loss within 2e-2 / 2e-3 relative of the two;
+gradients per large tensor: cosine > 0.93 against the emulation and > 0.80 against pure fp32 at 128 x 128 (at full size:
+>= 0.94 and no worse than the emulation's own cosine to fp32 minus 0.03) -- rounding the forward storage to bf16 moves the
+deep-layer gradients of a randomly initialised network to cosine ~0.90 from fp32 whatever computes them (DESIGN.md section 2);
+that the optimisation nevertheless follows the fp32 trajectory is checked over 30 steps in test_gpu_training.py.
 """
 import numpy as np
 import pytest
@@ -89,6 +93,12 @@ def test_train_step_fp32_matches_golden_and_fp64(tag):
         assert e_hip < max(4.0 * e_ref, 2e-5), (k, e_hip, e_ref)
         i = names.index(k)
         assert abs(float(prm.grad.double().norm()) - g["grad_norms"][i]) <= 3e-2 * g["grad_norms"][i] + 1e-7, k
+        # element level against numbers the LIVE reference produced: 64 strided samples of this gradient (tools/make_goldens.py)
+        probe = recipe.grad_probe(prm.grad.cpu()).double().numpy()
+        ref_probe = g["grad_probes"][i][:probe.size].astype(np.float64)
+        scale = n64 / np.sqrt(prm.numel())                    # RMS element of the tensor
+        tol = max(16.0 * e_ref, 1e-4) * scale * np.sqrt(probe.size) + 1e-9
+        assert float(np.linalg.norm(probe - ref_probe)) <= tol, (k, float(np.linalg.norm(probe - ref_probe)), tol)
     # running statistics were updated like nn.BatchNorm2d does
     run = np.concatenate([v.cpu().numpy().reshape(-1)[:8] for k, v in sorted(model.state_dict().items())
                           if k.endswith("running_mean") or k.endswith("running_var")])

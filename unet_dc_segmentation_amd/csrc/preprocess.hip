@@ -170,8 +170,10 @@ int launch_rolling_ball(const unsigned char* src, unsigned char* dst, int h, int
   const int lds = (PP_TILE + k) * (PP_TILE + k);
   hipLaunchKernelGGL(morph_kernel<false>, grid, dim3(256), lds, stream, src, eroded, h, w, cn, k, sp);
   hipLaunchKernelGGL(morph_kernel<true>, grid, dim3(256), lds, stream, eroded, bg, h, w, cn, k, sp);
-  // the eroded image is dead now: its first 32 bytes hold the per-channel min / max (int[4] each)
-  int* mn = reinterpret_cast<int*>(eroded);
+  // per-channel min / max (int[4] each) live in the 64 spare bytes behind the two planes (16-byte aligned): never inside a
+  // plane -- for images smaller than 32 bytes a scratch at the head of `eroded` would reach into `bg`, which
+  // subtract_minmax_kernel reads while the atomics write
+  int* mn = reinterpret_cast<int*>(ws + ((2L * h * w * cn + 15) & ~15L));
   int* mx = mn + 4;
   hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(64), 0, stream, mn, mx);
   const long npix = (long)h * w;

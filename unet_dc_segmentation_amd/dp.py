@@ -18,8 +18,12 @@ contiguous slices.  Slices are merged into buckets of ``bucket_bytes`` and all-r
 after waiting for the work already enqueued on the compute stream, so communication of
 decoder/bottleneck gradients overlaps the encoder backward kernels; ``finish()`` makes the compute
 stream wait for the outstanding collectives before autograd hands the gradients to the optimizer.
-Buckets of >= 16 MiB keep each xGMI link busy with few, large messages while leaving only the last
-~1 MB (enc2 + enc1 gradients) to be reduced after the backward pass has finished.
+Ready ranges arrive per STAGE (conv + BatchNorm parameters of one conv3x3 stage, one up-convolution, the head); they
+are merged until a bucket holds >= ``bucket_bytes`` (16 MiB) and cut at ``max_bucket_bytes`` (32 MiB), which keeps each
+xGMI link busy with few, large messages, lets the 37.7 MB of bottleneck.3 leave while bottleneck.0 still computes, and
+leaves only the last ~1 MB (enc2 + enc1 gradients) to be reduced after the backward pass has finished.  The resulting
+schedule for the U-Net-DC (fp32 bytes): 21.5 MB (head ... dec4.3) | 18.9 (dec4.0) | 23.0 + 23.0 (upconv4 + bottleneck.3)
+| 18.9 (bottleneck.0) | 17.7 (enc4 + enc3) | 1.0 (enc2 + enc1, flushed by finish()).
 """
 from __future__ import annotations
 
@@ -28,7 +32,8 @@ import torch.distributed as dist
 
 
 class DataParallel:
-    def __init__(self, model, process_group=None, bucket_bytes=16 << 20, broadcast=True, single_rank_collectives=False):
+    def __init__(self, model, process_group=None, bucket_bytes=16 << 20, broadcast=True, single_rank_collectives=False,
+                 max_bucket_bytes=32 << 20):
         """``single_rank_collectives``: issue the collectives even in a one-rank group (RCCL then runs every call of the
         exchange on one card: the rehearsal of the multi-GPU path that a one-GPU box allows, tests/test_gpu_dp.py)."""
         if not dist.is_initialized():
@@ -38,6 +43,8 @@ class DataParallel:
         self.world = dist.get_world_size(process_group)
         self.active = self.world > 1 or single_rank_collectives
         self.bucket_elems = max(1, bucket_bytes // 4)
+        self.max_elems = max(self.bucket_elems, max_bucket_bytes // 4)
+        self.schedule = []              # (elements) of every bucket launched in the current step (tests / DESIGN table)
         self.backend = dist.get_backend(process_group)
         self._works = []
         self._pending = None            # (flat, lo, hi) not yet launched
@@ -49,23 +56,45 @@ class DataParallel:
         model.grad_sync_finish = self.finish
 
     # -------------------------------------------------------------- replication
+    def _broadcast_coalesced(self, tensors):
+        """ONE broadcast per dtype over a flat copy (82 parameters / 54 buffers would otherwise be 136 / 54 collectives
+        of a few KB each)."""
+        groups = {}
+        for t in tensors:
+            groups.setdefault(t.dtype, []).append(t)
+        with torch.no_grad():
+            for ts in groups.values():
+                flat = torch.cat([t.detach().reshape(-1) for t in ts])
+                dist.broadcast(flat, src=0, group=self.pg)
+                o = 0
+                for t in ts:
+                    t.detach().copy_(flat[o:o + t.numel()].view_as(t))
+                    o += t.numel()
+        w = getattr(self.model, "_weights", None)
+        if w is not None:
+            w.invalidate()              # parameters were rewritten: the packed compute-type images follow at the next forward
+
     def broadcast_state(self):
         """Rank 0's parameters and buffers become everyone's (identical replicas at step 0)."""
-        with torch.no_grad():
-            for t in list(self.model.parameters()) + list(self.model.buffers()):
-                dist.broadcast(t.data, src=0, group=self.pg)
+        self._broadcast_coalesced(list(self.model.parameters()) + list(self.model.buffers()))
 
     def broadcast_buffers(self):
         """Rank 0's buffers (BatchNorm running_mean / running_var / num_batches_tracked) become everyone's."""
         if self.world == 1:
             return
-        with torch.no_grad():
-            for t in self.model.buffers():
-                dist.broadcast(t.data, src=0, group=self.pg)
+        self._broadcast_coalesced(list(self.model.buffers()))
 
     # -------------------------------------------------------------- gradient exchange
     def _launch(self, flat, lo, hi):
+        while hi - lo > self.max_elems:                  # cut from the top: that part has been ready longest
+            cut = max(lo + (hi - lo) // 2, hi - self.max_elems) if hi - lo <= 2 * self.max_elems else hi - self.max_elems
+            self._launch_one(flat, cut, hi)
+            hi = cut
+        self._launch_one(flat, lo, hi)
+
+    def _launch_one(self, flat, lo, hi):
         view = flat[lo:hi]
+        self.schedule.append(hi - lo)
         if self.backend == "nccl":
             work = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
             self._works.append((work, None))
@@ -79,6 +108,8 @@ class DataParallel:
         """Called by the backward schedule: gradients flat[lo:hi] are enqueued on the compute stream."""
         if not self.active:
             return
+        if not self._works and self._pending is None:
+            self.schedule = []                              # first range of a new step
         if self._pending is not None and self._pending[0] is flat and self._pending[1] == hi:
             lo, hi = lo, self._pending[2]                   # extend the pending range downwards
         elif self._pending is not None:

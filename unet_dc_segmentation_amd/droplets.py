@@ -38,6 +38,56 @@ def resize_mask_like_reference(mask, ow, oh):
     return resize_linear_cv2_u8(np.ascontiguousarray(mask, dtype=np.uint8), ow, oh)
 
 
+def mask_and_droplets_batch(probs, thresh, out_hws, min_area, max_droplets=1 << 14):
+    """probs: [B, H, W] fp32 probabilities on the HIP device; out_hws: B (oh, ow) pairs.  Every launch of the batch (mask,
+    union-find, per-label sums, compaction) is enqueued back to back on the current stream into ONE set of output
+    planes; the host then waits ONCE: one device->host copy brings the B droplet counts, a second the filled part of the
+    per-droplet integers.  Returns a list of (mask uint8 [oh, ow] DEVICE tensor, area int64 [n], centroid_row float64
+    [n], centroid_col float64 [n]) -- droplets in the reference's label order."""
+    if not probs.is_cuda or probs.dtype != torch.float32 or probs.dim() != 3:
+        raise _lib.UnetdcError("mask_and_droplets_batch needs a [B, H, W] fp32 tensor on the HIP device")
+    probs = probs.contiguous()
+    B, ph, pw = probs.shape
+    dev = probs.device
+    s = torch.cuda.current_stream().cuda_stream
+    lib = _lib.load()
+    out_hws = [(int(h), int(w)) for h, w in out_hws]
+    cap = int(min(max_droplets, max(h * w for h, w in out_hws)))
+    wsb = max(lib.unetdc_ccl_workspace(h, w) for h, w in out_hws)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)           # one workspace: the launches are stream-ordered
+    count = torch.zeros(B, dtype=torch.int32, device=dev)
+    area = torch.empty(B, cap, dtype=torch.int32, device=dev)
+    sums = torch.empty(2, B, cap, dtype=torch.int64, device=dev)
+    masks = []
+    for i, (oh, ow) in enumerate(out_hws):
+        mask = torch.empty(oh, ow, dtype=torch.uint8, device=dev)
+        p2 = probs[i]
+        if MASK_RESIZE == "nearest" or (ph == oh and pw == ow):      # same size: both rules are the identity
+            _lib.call("unetdc_mask_from_probs", p2.data_ptr(), ph, pw, float(thresh), mask.data_ptr(), oh, ow, s)
+        else:
+            from .preprocess import _resize_tables
+            xo, xa = _resize_tables(pw, ow, dev, True)
+            yo, ya = _resize_tables(ph, oh, dev, False)
+            _lib.call("unetdc_mask_from_probs_linear", p2.data_ptr(), ph, pw, float(thresh), mask.data_ptr(), oh, ow,
+                      xo.data_ptr(), xa.data_ptr(), yo.data_ptr(), ya.data_ptr(), s)
+        _lib.call("unetdc_ccl_stats", mask.data_ptr(), oh, ow, int(max(min_area, 1)), ws.data_ptr(), wsb,
+                  count[i:].data_ptr(), area[i].data_ptr(), sums[0, i].data_ptr(), sums[1, i].data_ptr(), None, cap, s)
+        masks.append(mask)
+    n = count.cpu().numpy().astype(np.int64)                        # the batch's only host wait
+    nmax = int(min(n.max(initial=0), cap))
+    a_h = area[:, :nmax].cpu().numpy().astype(np.int64)
+    s_h = sums[:, :, :nmax].cpu().numpy()
+    out = []
+    for i, (oh, ow) in enumerate(out_hws):
+        if n[i] > cap:                            # more droplets than the output capacity: this image again with room for all
+            out.append(mask_and_droplets(probs[i], thresh, (oh, ow), min_area, max_droplets=int(n[i])))
+            continue
+        a = a_h[i, :n[i]]
+        d = np.maximum(a, 1)
+        out.append((masks[i], a, s_h[0, i, :n[i]].astype(np.float64) / d, s_h[1, i, :n[i]].astype(np.float64) / d))
+    return out
+
+
 def mask_and_droplets(probs2d, thresh, out_hw, min_area, max_droplets=1 << 16):
     """probs2d: [H, W] fp32 probabilities on the HIP device.  Returns (mask uint8 [oh, ow] DEVICE tensor,
     area int64 [n], centroid_row float64 [n], centroid_col float64 [n]) -- droplets in the reference's label order."""

@@ -56,6 +56,92 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class PackedWeights:
+    """The K-contiguous compute-type weight images of ONE module (per device and compute type): ``w_fwd[9][Cout][Cin]`` /
+    ``w_dgrad[9][Cin][Cout]`` per 3x3 conv (taps flipped), ``w_fwd[4*Cout][Cin]`` / ``w_dgrad[4][Cin][Cout]`` per
+    ConvTranspose2d.  They depend on the parameters only, not on the input shape, so every engine of the module (one per
+    input shape, unet.py) reads the same set and the optimizer kernel (optim.FusedAdam) writes one set."""
+    _serials = __import__("itertools").count(1)
+
+    def __init__(self, model, device, tdtype, dt):
+        self.serial = next(PackedWeights._serials)     # identity that is never reused (id() of a freed object can be)
+        self.model, self.device, self.tdtype, self.dt = model, device, tdtype, dt
+        self.conv, self.up = {}, {}
+        widths = [64, 128, 256, 512, 1024]
+        prev = model.in_channels
+        for l, name in enumerate(ENCODER + ("bottleneck",)):
+            c = widths[l]
+            if l > 0:                                   # the C_in = 1/3 first layer reads the fp32 master directly
+                self._add_conv(name, 0, prev, c)
+            self._add_conv(name, 3, c, c)
+            prev = c
+        for lvl in (4, 3, 2, 1):
+            c = widths[lvl - 1]
+            self._add_conv(f"dec{lvl}", 0, 2 * c, c)
+            self._add_conv(f"dec{lvl}", 3, c, c)
+            self.up[lvl] = dict(mod=getattr(model, f"upconv{lvl}"), cin=2 * c, cout=c,
+                                w_fwd=torch.empty(4 * c * 2 * c, device=device, dtype=tdtype),
+                                w_dgrad=torch.empty(4 * c * 2 * c, device=device, dtype=tdtype))
+        self._versions = None          # parameter version counters the images were last built from
+        self._fresh_versions = None    # set by an optimizer that has just written the images itself
+        self._ptrs = None
+        self._trained = False          # a train-mode forward has run: optimizer steps may follow at any time
+
+    def _add_conv(self, block, idx, cin, cout):
+        conv = getattr(self.model, block)[idx]
+        self.conv[(block, idx)] = dict(mod=conv, cin=cin, cout=cout,
+                                       w_fwd=torch.empty(9 * cout * cin, device=self.device, dtype=self.tdtype),
+                                       w_dgrad=torch.empty(9 * cout * cin, device=self.device, dtype=self.tdtype))
+
+    def entries(self):
+        """(parameter, fwd image, dgrad image, a, b, kind) for every packed tensor, in a fixed order."""
+        ent = [(c["mod"].weight, c["w_fwd"], c["w_dgrad"], c["cout"], c["cin"], 0) for c in self.conv.values()]
+        ent += [(u["mod"].weight, u["w_fwd"], u["w_dgrad"], u["cin"], u["cout"], 1) for u in self.up.values()]
+        return ent
+
+    def invalidate(self):
+        """Force the next forward to rebuild the images (call after writing parameters through a path that bumps no
+        version counter)."""
+        self._versions = None
+
+    def fresh(self, versions):
+        """Called by an optimizer that writes the images itself (FusedAdam, optim.py) with the version counters of the
+        packed parameters at that moment: the next forward needs no re-pack IF those counters still stand (any write in
+        between -- load_state_dict, copy_, clamp_, an EMA swap -- bumps one of them and the images are rebuilt)."""
+        self._fresh_versions = tuple(versions)
+
+    def ensure(self, need_dgrad):
+        """Re-pack the images when they may be stale: ONE launch over a device-resident descriptor table.  Fused
+        optimizers such as torch.optim.Adam(fused=True) update parameters WITHOUT bumping their version counters, so
+        once a train-mode forward has run on this module (an optimizer may be stepping the parameters) the images are
+        rebuilt on every forward, eval-mode ones included (train fwd, eval fwd, opt.step(), eval fwd must not see stale
+        weights; the launch costs ~0.1 ms); in a pure-inference process the version counters (load_state_dict, copy_)
+        decide.  An optimizer that writes the images itself (optim.FusedAdam) announces it through fresh() and the pack
+        is skipped while the counters it saw still stand."""
+        import numpy as np
+        ent = self.entries()
+        versions = tuple(w._version for w, *_ in ent)
+        ptrs = tuple(w.data_ptr() for w, *_ in ent)
+        if self._ptrs != ptrs:
+            dt = np.dtype([("w", "<u8"), ("wf", "<u8"), ("wd", "<u8"), ("begin", "<i8"), ("a", "<i4"), ("b", "<i4"),
+                           ("kind", "<i4"), ("pad", "<i4")])
+            tab = np.zeros(len(ent), dtype=dt)
+            off = 0
+            for i, (w, wf, wd, a, b, kind) in enumerate(ent):
+                tab[i] = (w.data_ptr(), wf.data_ptr(), wd.data_ptr(), off, a, b, kind, 0)
+                off += (a // 32) * (b // 32)                 # 32 x 32 channel tiles of this tensor
+            self._table = torch.from_numpy(tab.view(np.uint8).copy()).to(self.device)
+            self._total, self._ptrs, self._versions = off, ptrs, None
+        self._trained = self._trained or need_dgrad
+        fresh, self._fresh_versions = self._fresh_versions, None
+        if fresh is not None and fresh == versions and self._versions is not None:
+            self._versions = versions          # the optimizer step wrote both images and nothing touched the parameters since
+            return
+        if self._trained or self._versions != versions:
+            call("unetdc_pack_many", self._table.data_ptr(), len(ent), self._total, self.dt, _stream())
+            self._versions = versions
+
+
 class _Stage:
     """One conv3x3 -> BatchNorm -> ReLU stage: parameters, packed weights, saved tensors."""
 
@@ -71,13 +157,12 @@ class _Stage:
             rows = _lib.load().unetdc_conv3x3_first_stats_rows(npix, cin, cout)
         else:
             rows = _lib.load().unetdc_conv3x3_stats_rows(npix, cout)
-            self.w_fwd = torch.empty(9 * cout * cin, device=dev, dtype=dt)
-            self.w_dgrad = torch.empty(9 * cout * cin, device=dev, dtype=dt)
+            img = eng.weights.conv[(block, idx)]
+            self.w_fwd, self.w_dgrad = img["w_fwd"], img["w_dgrad"]
         self.stat_rows = rows
         self.stats = torch.empty((rows + 64) * 2 * cout, **f32)
         self.scale, self.shift = torch.empty(cout, **f32), torch.empty(cout, **f32)
         self.mean, self.rstd = torch.empty(cout, **f32), torch.empty(cout, **f32)
-        self.packed_version = -1
         self.x_in = None      # input view of the last forward (for wgrad)
         self.a_out = None     # activated output view
         # BatchNorm-backward partial sums produced by the dgrad kernel that writes this stage's
@@ -90,7 +175,7 @@ class _Stage:
 
 
 class UNetEngine:
-    def __init__(self, model, x):
+    def __init__(self, model, x, weights=None):
         _lib.load()
         if not x.is_cuda:
             raise _lib.UnetdcError("UNetEngine needs a HIP device tensor")
@@ -105,6 +190,10 @@ class UNetEngine:
         self.dt = _lib.BF16 if self.dtype_name == "bf16" else _lib.F32
         self.tdtype = torch.bfloat16 if self.dtype_name == "bf16" else torch.float32
         self.oc = model.out_channels
+        # packed weight images: shared by every engine of the module (they do not depend on the input shape)
+        if weights is None or weights.device != self.device or weights.dt != self.dt or weights.model is not model:
+            weights = PackedWeights(model, self.device, self.tdtype, self.dt)
+        self.weights = weights
         self._build()
 
     # ------------------------------------------------------------------ construction
@@ -164,13 +253,8 @@ class UNetEngine:
             c = widths[lvl - 1]
             self.a0[f"dec{lvl}"] = torch.empty(self.npix[lvl - 1], c, device=dev, dtype=dt)
             self.a3[f"dec{lvl}"] = torch.empty(self.npix[lvl - 1], c, device=dev, dtype=dt)
-        # transposed convs: packed weights
-        self.up = {}
-        for lvl in (4, 3, 2, 1):
-            c = widths[lvl - 1]
-            self.up[lvl] = dict(mod=getattr(self.model, f"upconv{lvl}"), cin=2 * c, cout=c,
-                                w_fwd=torch.empty(4 * c * 2 * c, device=dev, dtype=dt),
-                                w_dgrad=torch.empty(4 * c * 2 * c, device=dev, dtype=dt), version=-1)
+        # transposed convs: module, sizes, packed weights (shared), input view of the last forward
+        self.up = {lvl: dict(self.weights.up[lvl]) for lvl in (4, 3, 2, 1)}
         # gradient-side buffers (allocated lazily on the first backward)
         self.grad_bufs = None
         # parameter order == model.parameters() order; flat gradient offsets
@@ -203,60 +287,10 @@ class UNetEngine:
         # recomputed); `generation` counts forwards so that a backward can tell whether ITS forward's activations
         # are still the ones in the buffers (see _UNetFunction.backward).
         self.generation = 0
-        self._trained = False          # a train-mode forward has run: optimizer steps may follow at any time
 
     # ------------------------------------------------------------------ weight caches
-    def _pack_entries(self):
-        """(parameter, fwd image, dgrad image, a, b, kind) for every packed tensor, in a fixed order."""
-        ent = []
-        for st in self.stages.values():
-            if not st.first:
-                ent.append((st.conv.weight, st.w_fwd, st.w_dgrad, st.cout, st.cin, 0))
-        for u in self.up.values():
-            ent.append((u["mod"].weight, u["w_fwd"], u["w_dgrad"], u["cin"], u["cout"], 1))
-        return ent
-
     def invalidate_weight_cache(self):
-        """Force the next forward to rebuild the packed weight images (call after writing parameters through a
-        path that bumps no version counter)."""
-        self._pack_versions = None
-
-    def weights_fresh(self, versions=None):
-        """Called by an optimizer that writes the packed images itself (FusedAdam, optim.py): the next forward
-        needs no re-pack."""
-        self._pack_fresh = True
-
-    def _pack(self, need_dgrad):
-        """Re-pack the K-contiguous compute-type weight images: ONE launch over a device-resident descriptor
-        table.  Fused optimizers such as torch.optim.Adam(fused=True) update parameters WITHOUT bumping their
-        version counters, so once a train-mode forward has run on this engine (an optimizer may be stepping the
-        parameters) the images are rebuilt on every forward, eval-mode ones included (train fwd, eval fwd,
-        opt.step(), eval fwd must not see stale weights; the launch costs ~0.1 ms); in a pure-inference process
-        the version counters (load_state_dict, copy_) decide.  An optimizer that writes the images itself
-        (unet_dc_segmentation_amd.optim.FusedAdam) announces it through weights_fresh() and the pack is skipped."""
-        import numpy as np
-        ent = self._pack_entries()
-        versions = tuple(w._version for w, *_ in ent)
-        ptrs = tuple(w.data_ptr() for w, *_ in ent)
-        if getattr(self, "_pack_ptrs", None) != ptrs:
-            dt = np.dtype([("w", "<u8"), ("wf", "<u8"), ("wd", "<u8"), ("begin", "<i8"), ("a", "<i4"), ("b", "<i4"),
-                           ("kind", "<i4"), ("pad", "<i4")])
-            tab = np.zeros(len(ent), dtype=dt)
-            off = 0
-            for i, (w, wf, wd, a, b, kind) in enumerate(ent):
-                tab[i] = (w.data_ptr(), wf.data_ptr(), wd.data_ptr(), off, a, b, kind, 0)
-                off += (a // 32) * (b // 32)                 # 32 x 32 channel tiles of this tensor
-            self._pack_table = torch.from_numpy(tab.view(np.uint8).copy()).to(self.device)
-            self._pack_total, self._pack_ptrs, self._pack_versions = off, ptrs, None
-        self._trained = self._trained or need_dgrad
-        if getattr(self, "_pack_fresh", False) and self._pack_versions is not None:
-            self._pack_fresh = False           # the optimizer step just wrote both images
-            self._pack_versions = versions
-            return
-        self._pack_fresh = False
-        if self._trained or self._pack_versions != versions:
-            call("unetdc_pack_many", self._pack_table.data_ptr(), len(ent), self._pack_total, self.dt, _stream())
-            self._pack_versions = versions
+        self.weights.invalidate()
 
     # ------------------------------------------------------------------ forward
     def run(self, x):
@@ -324,7 +358,7 @@ class UNetEngine:
 
     def forward(self, x, train):
         self.generation += 1               # every forward overwrites the activation buffers
-        self._pack(need_dgrad=train)
+        self.weights.ensure(need_dgrad=train)
         self._nbt = []
         s = _stream()
         N = self.N
@@ -493,18 +527,21 @@ class UNetEngine:
     def _block_bwd(self, name, flat, lvl, dskip, dpool, dx_out, colsum=None, skip_for=None):
         """stage 3 then stage 0 of a block; the gradient between them lives in the 'da' buffer."""
         da = self.grad_bufs[("da", lvl)]
-        self._stage_bwd(self.stages[(name, 3)], flat, lvl, dskip, dpool, da, fuse_prev=self.stages[(name, 0)])
-        self._stage_bwd(self.stages[(name, 0)], flat, lvl, da, None, dx_out, colsum=colsum, skip_for=skip_for)
-        self._notify(flat, name)
+        s3, s0 = self.stages[(name, 3)], self.stages[(name, 0)]
+        self._stage_bwd(s3, flat, lvl, dskip, dpool, da, fuse_prev=s0)
+        self._notify(flat, [s3.conv, s3.bn])             # per STAGE: bottleneck.3's 37.7 MB travel while bottleneck.0 computes
+        self._stage_bwd(s0, flat, lvl, da, None, dx_out, colsum=colsum, skip_for=skip_for)
+        self._notify(flat, [s0.conv, s0.bn])
 
-    def _notify(self, flat, name):
+    def _notify(self, flat, mods):
+        """Tell the data-parallel wrapper that the gradients of `mods` (adjacent in parameters() order) are enqueued."""
         hook = self.model.grad_ready_hook
         if hook is not None:
-            self._join_side()                            # the block's wgrads run on the side stream
-            mod = getattr(self.model, name)
-            ps = list(mod.parameters())
+            self._join_side()                            # the weight gradients may run on the side stream
+            ps = [q for m in mods for q in m.parameters()]
             lo = self.poffs[self.pindex[id(ps[0])]]
             hi = self.poffs[self.pindex[id(ps[-1])]] + ps[-1].numel()
+            assert hi - lo == sum(q.numel() for q in ps), "gradient ranges must be contiguous in the flat buffer"
             hook(flat, lo, hi)
 
     def backward(self, dprobs, probs):
@@ -530,7 +567,7 @@ class UNetEngine:
                  self.head_in.stride(0), oc.weight.data_ptr(), da.data_ptr(), da.stride(0),
                  self._gview(flat, oc.weight).data_ptr(), self._gview(flat, oc.bias).data_ptr(), ws, wsb,
                  N, self.H, self.W, 64, self.oc, self.dt, s)
-        self._notify(flat, "out_conv")
+        self._notify(flat, [self.model.out_conv])
         # decoder, level 1 (full resolution) up to level 4
         dact = da                               # gradient of the current block's activated output
         for lvl in (1, 2, 3, 4):
@@ -559,7 +596,7 @@ class UNetEngine:
             else:
                 call("unetdc_convT2x2_dgrad", dup.data_ptr(), dup.stride(0), u["w_dgrad"].data_ptr(),
                      dnext.data_ptr(), dnext.stride(0), N, h, w, u["cin"], c, self.dt, s)
-            self._notify(flat, f"upconv{lvl}")
+            self._notify(flat, [u["mod"]])
             dact = dnext
         # bottleneck: input is pool[4]
         self._block_bwd("bottleneck", flat, 4, dact, None, g[("dpool", 4)])

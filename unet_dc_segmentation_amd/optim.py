@@ -30,7 +30,11 @@ class FusedAdam(torch.optim.Optimizer):
             raise TypeError("FusedAdam takes the U-Net module (it needs the module's packed weight images), "
                             "not a parameter list")
         self.model = model
-        super().__init__(list(model.parameters()), dict(lr=lr, betas=betas, eps=eps))
+        # the full set of torch.optim.Adam defaults: a state_dict() of this class loads into torch.optim.Adam (whose
+        # step() reads every one of these keys from the group) and the other way round
+        super().__init__(list(model.parameters()),
+                         dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False, foreach=None,
+                              capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False))
         self.grad_scale = float(grad_scale)
         self._step = 0
         self._table = None
@@ -56,7 +60,19 @@ class FusedAdam(torch.optim.Optimizer):
             o += p.numel()
         self._n = n
 
+    def state_dict(self):
+        """torch.optim.Adam's layout: every parameter's entry carries its OWN ``step`` tensor (the shared counter object is
+        an internal economy; handing it out would make a non-fused torch Adam advance it once per parameter)."""
+        sd = super().state_dict()
+        for st in sd["state"].values():
+            if "step" in st:
+                st["step"] = torch.tensor(float(self._step))
+        return sd
+
     def load_state_dict(self, state_dict):
+        for g in state_dict.get("param_groups", ()):
+            if g.get("weight_decay", 0) or g.get("amsgrad", False) or g.get("maximize", False):
+                raise ValueError("FusedAdam implements plain Adam only (weight_decay=0, amsgrad=False, maximize=False)")
         super().load_state_dict(state_dict)
         params = self.param_groups[0]["params"]
         if params and "exp_avg" in self.state.get(params[0], {}):
@@ -69,11 +85,11 @@ class FusedAdam(torch.optim.Optimizer):
             self._table = None
 
     # ------------------------------------------------------------------ descriptor table
-    def _build_table(self, eng):
+    def _build_table(self, weights):
         params = self.param_groups[0]["params"]
         packed = {}
-        if eng is not None:
-            for w, wf, wd, a, b, kind in eng._pack_entries():
+        if weights is not None:
+            for w, wf, wd, a, b, kind in weights.entries():
                 packed[id(w)] = (wf, wd, a, b, kind)
         tab = np.zeros(len(params), dtype=_DESC)
         begin = 0
@@ -117,16 +133,20 @@ class FusedAdam(torch.optim.Optimizer):
         else:
             keep = torch.cat([p.grad.reshape(-1).float() for p in params])
             flat_ptr = keep.data_ptr()
-        eng = getattr(self.model, "_engine", None)
-        key = (id(eng), tuple(p.data_ptr() for p in params))
+        # the module's packed weight images (engine.PackedWeights: one set per module, shared by the engines of every input
+        # shape); keyed by its never-reused serial, not id(): a rebuilt object may be handed a freed one's address
+        weights = getattr(self.model, "_weights", None)
+        key = (getattr(weights, "serial", None), tuple(p.data_ptr() for p in params))
         if self._table is None or self._table_key != key:
-            self._build_table(eng)
+            self._build_table(weights)
             self._table_key = key
-        dt = eng.dt if eng is not None else _lib.F32
+        dt = weights.dt if weights is not None else _lib.F32
         _lib.call("unetdc_adam_step", self._table.data_ptr(), len(params), self._blocks, flat_ptr, float(lr), float(b1),
                   float(b2), float(eps), self._step, self.grad_scale, dt, torch.cuda.current_stream().cuda_stream)
-        if eng is not None:
-            eng.weights_fresh()                   # both packed images were just rewritten from the new parameters
+        if weights is not None:
+            # both packed images were just rewritten from the parameters as they are NOW: the next forward skips its own
+            # re-pack only while these version counters still stand (load_state_dict / copy_ / clamp_ after this step bump them)
+            weights.fresh(tuple(w._version for w, *_ in weights.entries()))
         self._step_t += 1
         return loss
 

@@ -57,7 +57,17 @@ def resize_to_input_device(img_u8, size):
     return out
 
 
+MAX_ELEMENT = 128          # csrc/preprocess.hip PP_MAXK: the structuring element and its halo must fit one LDS tile
+
+
 def preprocess_device(img_u8_host, radius, size, device="cuda"):
-    """numpy [H, W, 3] uint8 (a decoded image) -> network input [3, size, size] float32 on the device."""
+    """numpy [H, W, 3] uint8 (a decoded image) -> network input [3, size, size] float32 on the device.
+    A structuring element larger than the kernel's LDS tile allows (--background_radius > 128) takes the host operator for
+    the rolling ball only (utils.data_loader.rolling_ball_correction_rgb, the same arithmetic); resize, /255 and CHW stay
+    on the device."""
+    if int(radius) > MAX_ELEMENT:
+        from utils.data_loader import rolling_ball_correction_rgb
+        t = torch.from_numpy(np.ascontiguousarray(rolling_ball_correction_rgb(img_u8_host, int(radius)))).to(device)
+        return resize_to_input_device(t, size)
     t = torch.from_numpy(np.ascontiguousarray(img_u8_host)).to(device)
     return resize_to_input_device(rolling_ball_device(t, radius), size)

@@ -60,7 +60,8 @@ class _UNetFamily(nn.Module):
         #   "f32"  -- fp32 storage, exact-fp32 MFMA (parity configuration)
         #   "bf16" -- bf16 activations/weights, fp32 accumulate (throughput configuration)
         self.compute_dtype = "f32"
-        self._engine = None
+        self._engines = {}               # (device, input shape) -> engine.UNetEngine, most recently used last
+        self._weights = None             # engine.PackedWeights: compute-type weight images, shared by the engines
         self.grad_ready_hook = None      # set by the data-parallel wrapper (dp.py)
         self.grad_sync_finish = None
 
@@ -69,8 +70,30 @@ class _UNetFamily(nn.Module):
         if name not in ("f32", "bf16"):
             raise ValueError(f"compute dtype must be 'f32' or 'bf16', got {name!r}")
         self.compute_dtype = name
-        self._engine = None
+        self._engines, self._weights = {}, None
         return self
+
+    MAX_ENGINES = 3
+
+    def _engine_for(self, x):
+        """One engine (activation buffers, schedule) per input shape, a few kept alive: the ragged last validation batch of
+        train_DC_focal.py (its val_loader has no drop_last) must not free and re-allocate the training-shape buffers every
+        epoch.  The packed weight images are shared (engine.PackedWeights)."""
+        from . import engine                           # raises if libunetdc_hip.so is missing
+        key = (x.device, tuple(x.shape))
+        eng = self._engines.pop(key, None)
+        if eng is None or not eng.matches(x):
+            eng = engine.UNetEngine(self, x, weights=self._weights)
+            self._weights = eng.weights
+            while len(self._engines) >= self.MAX_ENGINES:
+                self._engines.pop(next(iter(self._engines)))          # least recently used
+        self._engines[key] = eng
+        return eng
+
+    @property
+    def _engine(self):
+        """The most recently used engine (None before the first HIP forward)."""
+        return next(reversed(self._engines.values()), None) if self._engines else None
 
     def dilation_of(self, block):
         return self.DILATIONS[block]
@@ -78,10 +101,7 @@ class _UNetFamily(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, x):
         if x.is_cuda:
-            from . import engine                       # raises if libunetdc_hip.so is missing
-            if self._engine is None or not self._engine.matches(x):
-                self._engine = engine.UNetEngine(self, x)
-            return self._engine.run(x)
+            return self._engine_for(x).run(x)
         return self._forward_aten_cpu(x)
 
     def _forward_aten_cpu(self, x):
