@@ -207,11 +207,12 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def executed_fraction(a, name):
-    """Fraction of the nominal taps the LDS-DMA conv kernel executes: a 256-pixel block of the flattened map skips a
-    tap when no pixel of the block can reach the image through it (block-level tap skipping, igemm_dma16.hip);
-    d = 16 on a 32 x 32 map executes 6 of 9 taps (an 8-row block reaches the image through the centre row of taps and
-    one of the two outer rows; 4 of 9 tap-pixel pairs are in bounds).  1.0 for transposed convs and the halo-patch kernel."""
+def executed_fraction(a, name, blocks16=False):
+    """Fraction of the nominal taps the LDS-DMA conv kernel executes: a 256-pixel block skips a tap when no pixel of the
+    block can reach the image through it (block-level tap skipping, igemm_dma16.hip).  Row-major blocks of the flattened
+    map (blocks16 False): d = 16 on a 32 x 32 map executes 6 of 9 taps (an 8-row block reaches the image through the
+    centre row of taps and one of the two outer rows).  16 x 16 pixel blocks (blocks16 True, the kernel's block order for
+    d % 16 == 0): exactly the in-bounds tap-pixel pairs, 4 of 9 there.  1.0 for transposed convs and the halo-patch kernel."""
     if "convT" in name:
         return 1.0
     if name == "unetdc_conv3x3_fwd":
@@ -225,6 +226,15 @@ def executed_fraction(a, name):
     else:
         return 1.0
     bm, live, total = 256, 0, 0
+    if blocks16:
+        for by in range(0, h, 16):
+            for bx in range(0, w, 16):
+                for t in range(9):
+                    dy, dx = (t // 3 - 1) * d, (t % 3 - 1) * d
+                    total += 1
+                    if by + 15 + dy >= 0 and by + dy < h and bx + 15 + dx >= 0 and bx + dx < w:
+                        live += 1
+        return live / total
     for m0 in range(0, h * w, bm):                        # blocks never straddle images when h*w % 256 == 0
         m1 = min(m0 + bm, h * w) - 1
         y0, x0, y1, x1 = m0 // w, m0 % w, m1 // w, m1 % w
@@ -541,7 +551,7 @@ def main():
             gsum[1] += ms
             gsum[2] += 1
             gsum[3] += nbytes
-            gsum[4] += fl * (executed_fraction(a, name) if "dma" in key else 1.0)
+            gsum[4] += fl * (executed_fraction(a, name, "blocks16x16" in key) if "dma" in key else 1.0)
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         kernels = []
         for key, (fl, ms, cnt, nbytes, flx) in groups.items():

@@ -50,6 +50,9 @@ CONV_CASES = [  # n, h, w, cin, cout, d
     (2, 128, 128, 256, 128, 4),  # d = 4: sixteen 32 x 32 sub-lattices per image, four K chunks
     (1, 64, 256, 64, 64, 2),     # d = 2 with the 4-wave configuration, fewer items than workgroups
     (1, 1024, 64, 64, 128, 1),   # tall narrow map: two tiles per row
+    # bf16: 16 x 16 pixel blocks as M tiles for d % 16 == 0 (igemm_dma16.hip, block order): every padded tap is skipped
+    (3, 48, 80, 128, 64, 16),    # 3 x 5 blocks per image, division-based block decode; border / inner blocks run 4 / 6 / 9 taps
+    (1, 64, 64, 64, 128, 32),    # d = 32 on a 64 x 64 map: a tap moves a block by two blocks
 ]
 
 
@@ -80,6 +83,8 @@ def test_conv3x3_fwd_dgrad_wgrad(dtype, case):
     np.testing.assert_allclose(stc[1].numpy(), (yq * yq).sum(dim=(0, 2, 3)).numpy(), rtol=1e-4, atol=1e-2)
     # rows that carry data (the persistent kernel writes one row per workgroup and zeros into the rest of the bound)
     live = _lib.load().unetdc_last_stats_rows()
+    if dtype == "bf16" and d % 16 == 0 and h % 16 == 0 and w % 16 == 0:
+        assert _lib.load().unetdc_last_kernel().decode().endswith("blocks16x16")        # routed to the block-order form
     assert 1 <= live <= rows
     sta = st.cpu()[: rows * 2 * cout].reshape(rows, 2, cout)
     assert torch.equal(sta[live:], torch.zeros_like(sta[live:]))
@@ -461,7 +466,8 @@ def test_pack_many_matches_per_layer_packers():
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("case", [(2, 16, 24, 64, 64, 1), (1, 32, 32, 128, 256, 4), (2, 256, 256, 64, 64, 1),
                                   (1, 512, 256, 128, 64, 2), (2, 96, 160, 64, 64, 1), (2, 48, 80, 128, 128, 1),
-                                  (2, 128, 128, 256, 128, 1), (3, 512, 256, 64, 64, 1), (1, 128, 128, 128, 128, 4)])
+                                  (2, 128, 128, 256, 128, 1), (3, 512, 256, 64, 64, 1), (1, 128, 128, 128, 128, 4),
+                                  (4, 32, 32, 256, 256, 16), (2, 48, 64, 128, 64, 16)])   # d = 16: 16 x 16 block order (bf16)
 def test_dgrad_with_fused_bn_backward_statistics(dtype, case):
     """conv dgrad whose epilogue also emits the BatchNorm-backward partial sums of the consuming stage
     (S1 = sum dx*[n>0], S2 = sum dx*[n>0]*xhat), and bn_relu_bwd consuming them instead of its own pass."""

@@ -15,6 +15,13 @@
 //   accumulator    : acc[i][j][v] = out[pixel 16*i + 4*rb + v][channel 4*c + j]: the B rows are ordered so that
 //                    the FOUR N tiles of a wave hold the four consecutive channels 4c..4c+3 -- a lane packs them
 //                    into one 8-byte store and 16 lanes write one whole 128-byte pixel row.
+//
+// BLOCK ORDER OF THE M INDEX (quad_bpr > 0; strongly dilated layers, d a multiple of 16): a workgroup's 256 rows are one
+// 16 x 16 pixel block of one image instead of 256 consecutive pixels of the flattened map.  A tap of dilation d moves such
+// a block by whole blocks, so it lies either entirely inside the image or entirely outside: the block-level tap mask then
+// skips EVERY padded tap-pixel pair -- d = 16 on the 32 x 32 bottleneck map runs 4 of 9 taps per block (6 of 9 with
+// row-major blocks, which can only skip whole rows of taps) and 25 / 36 on a 64 x 64 map.  Only addresses change: an MFMA
+// tile is still 16 consecutive pixels of one image row.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -52,8 +59,16 @@ __global__ __launch_bounds__(512, 2) void igemm_dma16_kernel(const IgemmParams p
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, wbytes, 0x00020000);
 
   const bool p2 = p.wo_shift >= 0;
+  const bool quad = p.quad_bpr > 0;
   auto decode = [&](int m, int& n, int& oy, int& ox) {
-    if (p2) {
+    if (quad) {
+      const int blk = m >> 8, r = m & 255;
+      n = blk / p.quad_bpi;
+      const int b = blk - n * p.quad_bpi;
+      const int qy = b / p.quad_bpr;
+      oy = qy * 16 + (r >> 4);
+      ox = (b - qy * p.quad_bpr) * 16 + (r & 15);
+    } else if (p2) {
       n = m >> p.howo_shift;
       const int rem = m & (HoWo - 1);
       oy = rem >> p.wo_shift;
@@ -74,7 +89,7 @@ __global__ __launch_bounds__(512, 2) void igemm_dma16_kernel(const IgemmParams p
     int by0 = 0, by1 = p.Ho - 1, bx0 = 0, bx1 = p.Wo - 1;
     if (na == nb) {
       by0 = ya; by1 = yb;
-      if (ya == yb) { bx0 = xa; bx1 = xb; }
+      if (ya == yb || quad) { bx0 = xa; bx1 = xb; }       // block order: first and last pixel are opposite corners of the block
     }
     for (int t = 0; t < p.ntaps; ++t) {
       const int iy0 = by0 * p.stride + p.offy[t], iy1 = by1 * p.stride + p.offy[t];
@@ -213,8 +228,14 @@ __global__ __launch_bounds__(512, 2) void igemm_dma16_kernel(const IgemmParams p
     for (int i = 0; i < TMT; ++i) {
       const int mb = m0 + (wm * TMT + i) * 16;
       tile_ok[i] = mb < p.M;
-      voff[i] = (unsigned)(mb + 4 * rb) * ldob + (unsigned)(col * ES);
-      yoff[i] = (unsigned)(mb + 4 * rb) * ldyb + (unsigned)(col * ES);
+      int pix = mb;                                         // output pixel of the tile's first row (16 consecutive pixels either way)
+      if (quad) {
+        int n, oy, ox;
+        decode(mb, n, oy, ox);
+        pix = (n * p.Ho + oy) * p.Wo + ox;
+      }
+      voff[i] = (unsigned)(pix + 4 * rb) * ldob + (unsigned)(col * ES);
+      yoff[i] = (unsigned)(pix + 4 * rb) * ldyb + (unsigned)(col * ES);
     }
   }
   float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -245,10 +266,20 @@ static int launch_dma16_cfg(IgemmParams& p, hipStream_t stream) {
   }
   p.mblocks = ceil_div(p.M, BM);
   p.nblocks = p.Cout / BN;
+  // 16 x 16 pixel blocks as M tiles for strongly dilated 3 x 3 convolutions (header comment): every padded tap-pixel pair is skipped
+  static int quad_on = -1;                               // UNETDC_QUAD=0: row-major blocks (A/B measurements)
+  if (quad_on < 0) { const char* e = getenv("UNETDC_QUAD"); quad_on = (e && e[0] == '0') ? 0 : 1; }
+  p.quad_bpr = p.quad_bpi = 0;
+  if (quad_on && BM == 256 && p.ntaps == 9 && p.stride == 1 && p.mode != MODE_SHUFFLE && p.Ho == p.Hi && p.Wo == p.Wi &&
+      p.offy[8] >= 16 && p.offy[8] % 16 == 0 && p.offx[8] == p.offy[8] && p.Ho % 16 == 0 && p.Wo % 16 == 0 &&
+      p.M % ((long)p.Ho * p.Wo) == 0) {
+    p.quad_bpr = p.Wo / 16;
+    p.quad_bpi = (p.Ho / 16) * p.quad_bpr;
+  }
   const long nwg = (long)p.mblocks * p.nblocks;
   hipLaunchKernelGGL((igemm_dma16_kernel<WM, WN, TMT>), dim3((unsigned)nwg), dim3(WM * WN * 64), LDS, stream, p);
   char nm[96];
-  snprintf(nm, sizeof(nm), "igemm_dma16_kernel<%d, %d, %d>", WM, WN, TMT);
+  snprintf(nm, sizeof(nm), "igemm_dma16_kernel<%d, %d, %d>%s", WM, WN, TMT, p.quad_bpr ? " blocks16x16" : "");
   note_kernel(nm);
   return check_launch("igemm_dma16_kernel");
 }

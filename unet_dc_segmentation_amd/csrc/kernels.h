@@ -25,6 +25,7 @@ struct IgemmParams {
   int M, Ho, Wo, Hi, Wi, Cin, Cout, ldx, ldo, ntaps, stride, mode, shuf_c;
   int mblocks, nblocks;
   int wo_shift, howo_shift;  // log2(Wo), log2(Ho*Wo) when both are powers of two, else -1 (set by launch_igemm)
+  int quad_bpr, quad_bpi;    // > 0: the M index walks 16 x 16 pixel blocks (blocks per image row / per image), see igemm_dma16.hip
   int offy[9];
   int offx[9];
 };
@@ -83,6 +84,7 @@ struct ApplyParams {
   const void* y; void* a; void* pooled;
   const float* scale; const float* shift;
   int N, H, W, C, ldy, lda, ldp;
+  int nt;                  // 1: streaming (nt) loads of y
 };
 struct BnBwdParams {
   const void* dskip; const void* dpool; const void* y; void* dy;
@@ -90,6 +92,7 @@ struct BnBwdParams {
   const float* k1; const float* k2; const float* k3;
   float* parts;            // [gridDim.x][3][C]
   int N, H, W, C, lds, ldp, ldy, lddy;
+  int nt;                  // 1: streaming (nt) loads of y and of the incoming gradient in the apply pass (their last use)
 };
 struct HeadParams {
   const void* a; const float* w; const float* b; float* probs;

@@ -43,7 +43,11 @@ FUSE_POOL_SKIP = os.environ.get("UNETDC_FUSE_POOL_SKIP", "0") == "1" and FUSE_CO
 # chain, on a side HIP stream.  Measured +0.6 % on MI355X (the MFMA kernels fill the CUs' LDS, so little
 # co-residency with the HBM-bound BatchNorm passes); off by default because overlapping kernels make
 # per-kernel timings (bench.py roofline leg, rocprofv3) unattributable.
-SIDE_WGRAD = os.environ.get("UNETDC_SIDE_WGRAD", "0") == "1"
+SIDE_WGRAD = os.environ.get("UNETDC_SIDE_WGRAD", "0") in ("1", "2")
+# "2": the side stream picks a stage's weight gradient up only AFTER that stage's dgrad has been enqueued on the main stream,
+# so the MFMA-bound weight gradient runs beside the HBM-bound BatchNorm backward of the NEXT stage instead of competing
+# with its own dgrad for the matrix pipes (experiment)
+SIDE_DEFER = os.environ.get("UNETDC_SIDE_WGRAD", "0") == "2"
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
@@ -411,7 +415,7 @@ class UNetEngine:
             st.dy = torch.empty(st.npix, st.cout, device=dev, dtype=dt)
         self.grad_bufs = g
         self.workspace = torch.empty(self.ws_bytes, device=dev, dtype=torch.uint8)
-        self.side = torch.cuda.Stream(device=dev) if SIDE_WGRAD else None
+        self.side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("UNETDC_SIDE_PRIO", "0"))) if SIDE_WGRAD else None
         self.ws_side = torch.empty(self.ws_bytes, device=dev, dtype=torch.uint8) if SIDE_WGRAD else self.workspace
 
     def _side_after_main(self):
@@ -485,13 +489,23 @@ class UNetEngine:
     def _stage_bwd_rest(self, st, flat, lvl, dx_out, fuse_prev, colsum, skip_for, dy, ws, wsb, N, h, w, s):
         dw = self._gview(flat, st.conv.weight)
         xin = st.x_in
-        with self._side_after_main() as (s2, ws2):
-            if st.first:
-                call("unetdc_conv3x3_first_wgrad", xin.data_ptr(), dy.data_ptr(), dy.stride(0), dw.data_ptr(), ws2, wsb,
-                     N, h, w, st.cin, st.cout, st.dil, self.dt, s2)
-            else:
-                call("unetdc_conv3x3_wgrad", xin.data_ptr(), xin.stride(0), dy.data_ptr(), dy.stride(0), dw.data_ptr(),
-                     ws2, wsb, N, h, w, st.cin, st.cout, st.dil, self.dt, s2)
+
+        def wgrad():
+            with self._side_after_main() as (s2, ws2):
+                if st.first:
+                    call("unetdc_conv3x3_first_wgrad", xin.data_ptr(), dy.data_ptr(), dy.stride(0), dw.data_ptr(), ws2, wsb,
+                         N, h, w, st.cin, st.cout, st.dil, self.dt, s2)
+                else:
+                    call("unetdc_conv3x3_wgrad", xin.data_ptr(), xin.stride(0), dy.data_ptr(), dy.stride(0), dw.data_ptr(),
+                         ws2, wsb, N, h, w, st.cin, st.cout, st.dil, self.dt, s2)
+
+        if not SIDE_DEFER:
+            wgrad()
+        self._stage_dgrad(st, dx_out, fuse_prev, colsum, skip_for, dy, ws, wsb, N, h, w, s)
+        if SIDE_DEFER:
+            wgrad()
+
+    def _stage_dgrad(self, st, dx_out, fuse_prev, colsum, skip_for, dy, ws, wsb, N, h, w, s):
         if not st.first:
             if dx_out is not None and fuse_prev is not None and FUSE_BN_BWD:
                 call("unetdc_conv3x3_dgrad_bnstats", dy.data_ptr(), dy.stride(0), st.w_dgrad.data_ptr(),
