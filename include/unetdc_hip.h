@@ -198,6 +198,12 @@ int unetdc_convT2x2_dgrad_bnstats(const void* dup, int lddup, const void* w_dgra
  * w [OC][C] fp32, probs/dprobs NCHW fp32 [n][OC][h][w]. */
 int unetdc_head_fwd(const void* a, int lda, const float* w, const float* b, float* probs, int n, int h, int wd,
                     int c, int oc, int dtype, unetdc_stream_t s);
+/* The same head fed from the RAW conv output y of the stage in front of it (dec1's second stage, models/model_2.py:76-79):
+ * that stage's BatchNorm + ReLU, a = relu(scale * y + shift) (models/model_2.py:52-53), is applied while loading, rounded
+ * through the storage type like a stored activation would be -- the activation tensor itself is never written or read
+ * (train-mode forward; the eval-mode convolution folds BatchNorm into its own epilogue and feeds unetdc_head_fwd). */
+int unetdc_head_fwd_bn(const void* y, int ldy, const float* scale, const float* shift, const float* w, const float* b,
+                       float* probs, int n, int h, int wd, int c, int oc, int dtype, unetdc_stream_t s);
 int64_t unetdc_head_bwd_workspace(int n, int h, int w, int c, int oc, int dtype);
 int unetdc_head_bwd(const float* dprobs, const float* probs, const void* a, int lda, const float* w, void* da,
                     int ldda, float* dw, float* db, void* workspace, int64_t workspace_bytes, int n, int h, int wd,
@@ -205,7 +211,8 @@ int unetdc_head_bwd(const float* dprobs, const float* probs, const void* a, int 
 /* head_bwd that also produces the BatchNorm-backward partial sums of the stage whose activated output `a` is (the
  * block feeding out_conv, models/model_2.py:76-79), in the layout unetdc_bn_relu_bwd takes as pre_parts: the
  * gradient da is then read once by that stage's backward instead of twice.  y_prev/scale/shift/mean/rstd: that
- * stage's saved conv output and batch statistics; parts needs (rows + 64) * 3 * c floats, *nparts receives rows. */
+ * stage's saved conv output and batch statistics; parts needs (rows + 64) * 3 * c floats, *nparts receives rows.
+ * a == NULL: the activation is recomputed from y_prev / scale / shift (the counterpart of unetdc_head_fwd_bn). */
 int unetdc_head_bwd_bnstats(const float* dprobs, const float* probs, const void* a, int lda, const float* w, void* da,
                             int ldda, float* dw, float* db, void* workspace, int64_t workspace_bytes, const void* y_prev,
                             int ldy_prev, const float* scale, const float* shift, const float* mean, const float* rstd,

@@ -393,10 +393,23 @@ def test_head_bwd_fused_bn_backward_sums(dtype, shape):
     parts = torch.full(((rows + 64) * 3 * c,), float("nan"), device="cuda")
     dv = [t.cuda() for t in (scale, shift, mean, rstd)]
     npar = ctypes.c_int(0)
-    for fused in (False, True):
+    # normalise-on-load forward: the head fed from the raw conv output == the head fed from the stored activation, bit for bit
+    bd2 = (torch.randn(oc, generator=g) * 0.1).cuda()
+    p_a, p_y = (torch.full((n, oc, h, w), float("nan"), device="cuda") for _ in range(2))
+    call("unetdc_head_fwd", av.data_ptr(), av.stride(0), wd2.data_ptr(), bd2.data_ptr(), p_a.data_ptr(), n, h, w, c, oc,
+         G.DT[dtype], G.stream())
+    call("unetdc_head_fwd_bn", yv.data_ptr(), yv.stride(0), dv[0].data_ptr(), dv[1].data_ptr(), wd2.data_ptr(), bd2.data_ptr(),
+         p_y.data_ptr(), n, h, w, c, oc, G.DT[dtype], G.stream())
+    assert torch.equal(p_a, p_y)
+    for fused in (False, True, "from_y"):
         dav = G.empty_nhwc(n * h * w, c, dtype)
         dw, db = torch.full((oc, c), float("nan"), device="cuda"), torch.full((oc,), float("nan"), device="cuda")
-        if fused:
+        if fused == "from_y":                            # a == NULL: the activation is recomputed from y / scale / shift
+            call("unetdc_head_bwd_bnstats", dp.data_ptr(), probs.data_ptr(), None, c, wd2.data_ptr(),
+                 dav.data_ptr(), dav.stride(0), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nbytes, yv.data_ptr(),
+                 yv.stride(0), dv[0].data_ptr(), dv[1].data_ptr(), dv[2].data_ptr(), dv[3].data_ptr(), parts.data_ptr(),
+                 parts.numel(), ctypes.byref(npar), n, h, w, c, oc, G.DT[dtype], G.stream())
+        elif fused:
             call("unetdc_head_bwd_bnstats", dp.data_ptr(), probs.data_ptr(), av.data_ptr(), av.stride(0), wd2.data_ptr(),
                  dav.data_ptr(), dav.stride(0), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nbytes, yv.data_ptr(),
                  yv.stride(0), dv[0].data_ptr(), dv[1].data_ptr(), dv[2].data_ptr(), dv[3].data_ptr(), parts.data_ptr(),
@@ -408,6 +421,7 @@ def test_head_bwd_fused_bn_backward_sums(dtype, shape):
         torch.cuda.synchronize()
         outs.append((dav.clone(), dw.clone(), db.clone()))
     assert torch.equal(outs[0][0], outs[1][0])               # da: bitwise
+    assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1]) and torch.equal(outs[1][2], outs[2][2])
     for u, v in zip(outs[0][1:], outs[1][1:]):               # dw, db: the fused launch may take fewer workgroups (rows of `parts`)
         assert rel(u.cpu(), v.cpu()) < 1e-5
     assert 1 <= npar.value <= rows + 64

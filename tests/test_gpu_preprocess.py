@@ -18,7 +18,7 @@ def _image(rng, h, w, c):
 
 
 @pytest.mark.parametrize("case", [(96, 130, 3, 15), (257, 301, 3, 50), (64, 64, 1, 1), (200, 90, 3, 2), (150, 150, 4, 127),
-                                  (1040, 1388, 3, 50)])
+                                  (1040, 1388, 3, 50), (7, 5, 3, 3), (40, 33, 2, 9), (130, 70, 1, 128)])
 def test_rolling_ball_matches_numpy_restatement(case):
     from unet_dc_segmentation_amd.preprocess import rolling_ball_device
     from utils.data_loader import rolling_ball_correction_rgb

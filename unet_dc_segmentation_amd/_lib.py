@@ -52,6 +52,7 @@ SIGNATURES = {
     "unetdc_conv3x3_dgrad_bnstats": (I, [P, I, P, P, I, P, I, P, P, P, P, P, L, P, I, I, I, I, I, I, I, P]),
     "unetdc_convT2x2_dgrad_bnstats": (I, [P, I, P, P, I, P, I, P, P, P, P, P, L, P, I, I, I, I, I, I, P]),
     "unetdc_head_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, P]),
+    "unetdc_head_fwd_bn": (I, [P, I, P, P, P, P, P, I, I, I, I, I, I, P]),
     "unetdc_head_bwd_workspace": (L, [I, I, I, I, I, I]),
     "unetdc_head_bwd": (I, [P, P, P, I, P, P, I, P, P, P, L, I, I, I, I, I, I, P]),
     "unetdc_head_bwd_bnstats": (I, [P, P, P, I, P, P, I, P, P, P, L, P, I, P, P, P, P, P, L, P, I, I, I, I, I, I, P]),

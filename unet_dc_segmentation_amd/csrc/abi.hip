@@ -341,6 +341,16 @@ int unetdc_head_fwd(const void* a, int lda, const float* w, const float* b, floa
   return launch_head_fwd(p, dtype, (hipStream_t)s);
 }
 
+int unetdc_head_fwd_bn(const void* y, int ldy, const float* scale, const float* shift, const float* w, const float* b,
+                       float* probs, int n, int h, int wd, int c, int oc, int dtype, unetdc_stream_t s) {
+  GEOM_CHECK(n, h, wd);
+  UNETDC_REQUIRE(y && scale && shift, "head_fwd_bn: null pointer");
+  HeadParams p{};
+  p.a = y; p.w = w; p.b = b; p.probs = probs; p.N = n; p.H = h; p.W = wd; p.C = c; p.OC = oc; p.lda = ldy;
+  p.bn_scale = scale; p.bn_shift = shift;
+  return launch_head_fwd(p, dtype, (hipStream_t)s);
+}
+
 int64_t unetdc_head_bwd_workspace(int n, int h, int w, int c, int oc, int dtype) {
   return head_bwd_workspace_bytes(n, h, w, c, oc, dtype);
 }

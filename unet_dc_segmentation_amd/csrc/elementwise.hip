@@ -319,7 +319,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 // Head: 1x1 conv (C -> OC) + sigmoid (models/model_2.py:32,79-80), probabilities out in NCHW fp32.
 // C/EPC lanes cooperate on one pixel (C = 64: 8 lanes bf16 / 16 lanes fp32), shuffle-reduced.
 // ================================================================================================
-template <typename T>
+// NORM: `a` is the raw conv output of the producing stage and the BatchNorm + ReLU of that stage is applied on load,
+// a = relu(scale * y + shift) rounded through the storage type (exactly the values a stand-alone normalisation pass
+// would have stored): the activation tensor is never written or read.
+template <typename T, bool NORM>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadParams p) {
   constexpr int EPC = Chunk<T>::N;
   constexpr int UNR = 4;                              // pixels per lane group and trip: four 16-byte loads in flight
@@ -328,6 +331,11 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadParams p) {
   const int tid = threadIdx.x, cl = tid % cpp, pl = tid / cpp;
   const long HW = (long)p.H * p.W, P = (long)p.N * HW;
   const T* __restrict__ ag = reinterpret_cast<const T*>(p.a);
+  float nsc[EPC], nsh[EPC];
+  if (NORM) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { nsc[e] = p.bn_scale[cl * EPC + e]; nsh[e] = p.bn_shift[cl * EPC + e]; }
+  }
   for (long pb = (long)blockIdx.x * ppb * UNR; pb < P; pb += (long)gridDim.x * ppb * UNR) {
     float v[UNR][EPC];
     long pix[UNR];
@@ -335,6 +343,12 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadParams p) {
     for (int u = 0; u < UNR; ++u) {
       pix[u] = pb + u * ppb + pl;
       if (pix[u] < P) Chunk<T>::unpack(ld16(ag + pix[u] * p.lda + cl * EPC), v[u]);
+    }
+    if (NORM) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[u][e] = round_through<T>(fmaxf(fmaf(v[u][e], nsc[e], nsh[e]), 0.f));
     }
     for (int oc = 0; oc < p.OC; ++oc) {
       float wv[EPC];
@@ -398,8 +412,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadParams p) {
       const float pr = p.probs[o];
       const float dz = p.dprobs[o] * pr * (1.f - pr);
       float av[EPC], d[EPC], yv[EPC];
-      Chunk<T>::unpack(ld16(ag + pix * p.lda + cl * EPC), av);
-      if (BN && last) Chunk<T>::unpack(ld16(yg + pix * p.bn_ldy + cl * EPC), yv);
+      if (BN && (last || !ag)) Chunk<T>::unpack(ld16(yg + pix * p.bn_ldy + cl * EPC), yv);
+      if (!BN || ag) Chunk<T>::unpack(ld16(ag + pix * p.lda + cl * EPC), av);
+      else {                                             // the activation as the forward pass saw it, from the saved conv output
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) av[e] = round_through<T>(fmaxf(fmaf(yv[e], sc[e], sh[e]), 0.f));
+      }
       if (oc > 0) Chunk<T>::unpack(ld16(dag + pix * p.ldda + cl * EPC), d);
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
@@ -838,7 +856,7 @@ long head_bwd_workspace_bytes(int N, int H, int W, int C, int OC, int dtype) {
 static int check_head(const HeadParams& p, int dtype) {
   const int epc = dtype == UNETDC_BF16 ? 8 : 4;
   UNETDC_REQUIRE(dtype == UNETDC_F32 || dtype == UNETDC_BF16, "head: bad dtype %d", dtype);
-  UNETDC_REQUIRE(p.a && p.w && p.probs, "head: null pointer");
+  UNETDC_REQUIRE((p.a || p.bn_y) && p.w && p.probs, "head: null pointer");
   const int cpp = p.C / epc;
   UNETDC_REQUIRE(p.C % epc == 0 && cpp >= 1 && cpp <= 64 && (cpp & (cpp - 1)) == 0,
                  "head: C=%d unsupported (C/%d must be a power of two <= 64)", p.C, epc);
@@ -852,8 +870,15 @@ int launch_head_fwd(HeadParams& p, int dtype, hipStream_t stream) {
   UNETDC_REQUIRE(p.b != nullptr, "head: null bias");
   const int epc = dtype == UNETDC_BF16 ? 8 : 4;
   const int nb = grid_for((long)p.N * p.H * p.W, 4 * (256 / (p.C / epc)));     // UNR = 4 pixels per lane group and trip
-  if (dtype == UNETDC_BF16) hipLaunchKernelGGL(head_fwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL(head_fwd_kernel<float>, dim3(nb), dim3(256), 0, stream, p);
+  const bool norm = p.bn_scale != nullptr;             // BatchNorm + ReLU of the producing stage applied on load
+  if (norm) UNETDC_REQUIRE(p.bn_shift != nullptr, "head_fwd_bn: null shift");
+  if (dtype == UNETDC_BF16) {
+    if (norm) hipLaunchKernelGGL((head_fwd_kernel<bf16_t, true>), dim3(nb), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((head_fwd_kernel<bf16_t, false>), dim3(nb), dim3(256), 0, stream, p);
+  } else {
+    if (norm) hipLaunchKernelGGL((head_fwd_kernel<float, true>), dim3(nb), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((head_fwd_kernel<float, false>), dim3(nb), dim3(256), 0, stream, p);
+  }
   return check_launch("head_fwd_kernel");
 }
 
@@ -866,6 +891,7 @@ int launch_head_bwd(HeadParams& p, float* dw, float* db, void* workspace, long w
   UNETDC_REQUIRE(p.ldda % epc == 0, "head_bwd: ldda not chunk aligned");
   int nb = head_blocks((long)p.N * p.H * p.W, p.C / epc);
   const bool bn = p.bn_y != nullptr;
+  UNETDC_REQUIRE(bn || p.a, "head_bwd: null activation");
   if (bn) {
     UNETDC_REQUIRE(p.bn_scale && p.bn_shift && p.bn_mean && p.bn_rstd && p.bn_parts && bn_nparts,
                    "head_bwd_bnstats: null pointer");

@@ -39,6 +39,10 @@ FUSE_COLSUM = os.environ.get("UNETDC_FUSE_COLSUM", "1") != "0"
 # 0.08 ms cheaper per step and the four decoder dgrads 0.06 + 0.03 ms dearer (their epilogue now also reads the encoder's
 # saved outputs): no net gain, so the default keeps the two-pass form over dskip + dpool.
 FUSE_POOL_SKIP = os.environ.get("UNETDC_FUSE_POOL_SKIP", "0") == "1" and FUSE_COLSUM and FUSE_BN_BWD
+# The head reads dec1's RAW conv output and applies that stage's BatchNorm + ReLU on load (unetdc_head_fwd_bn; the backward
+# recomputes the activation the same way): dec1.3's normalisation pass and its 268 MB activation tensor disappear from the
+# training step.  UNETDC_FUSE_HEAD_BN=0: stand-alone pass (A/B switch)
+FUSE_HEAD_BN = os.environ.get("UNETDC_FUSE_HEAD_BN", "1") != "0" and FUSE_BN_BWD
 # Opt-in (UNETDC_SIDE_WGRAD=1): run the weight-gradient kernels, which hang off the backward critical
 # chain, on a side HIP stream.  Measured +0.6 % on MI355X (the MFMA kernels fill the CUs' LDS, so little
 # co-residency with the HBM-bound BatchNorm passes); off by default because overlapping kernels make
@@ -314,9 +318,10 @@ class UNetEngine:
             return _UNetFunction.apply(x, self, *self.params)
         return self.forward(x, train=False)
 
-    def _stage_fwd(self, st, xin, dst, train, pooled=None):
+    def _stage_fwd(self, st, xin, dst, train, pooled=None, apply=True):
         """conv -> BN -> ReLU.  xin: [npix, cin] view (or the NCHW image for the first stage);
-        dst: [npix, cout] view receiving the activation; pooled: optional [npix/4, cout] view."""
+        dst: [npix, cout] view receiving the activation; pooled: optional [npix/4, cout] view;
+        apply=False (train mode only): stop after the batch statistics -- the consumer normalises on load."""
         s = _stream()
         N = self.N
         h, w = st.hw
@@ -341,9 +346,10 @@ class UNetEngine:
                  st.mean.data_ptr(), st.rstd.data_ptr(), st.cout, s)
             if track:
                 self._nbt.append(bn.num_batches_tracked)       # incremented together at the end of forward()
-            call("unetdc_bn_relu_apply", y.data_ptr(), y.stride(0), st.scale.data_ptr(), st.shift.data_ptr(),
-                 dst.data_ptr(), dst.stride(0), _ptr(pooled), pooled.stride(0) if pooled is not None else 0,
-                 N, h, w, st.cout, self.dt, s)
+            if apply:
+                call("unetdc_bn_relu_apply", y.data_ptr(), y.stride(0), st.scale.data_ptr(), st.shift.data_ptr(),
+                     dst.data_ptr(), dst.stride(0), _ptr(pooled), pooled.stride(0) if pooled is not None else 0,
+                     N, h, w, st.cout, self.dt, s)
         else:
             call("unetdc_bn_eval_affine", bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
                  bn.running_var.data_ptr(), conv.bias.data_ptr(), bn.eps, st.scale.data_ptr(), st.shift.data_ptr(),
@@ -386,13 +392,20 @@ class UNetEngine:
             call("unetdc_convT2x2_fwd", hin.data_ptr(), hin.stride(0), u["w_fwd"].data_ptr(),
                  u["mod"].bias.data_ptr(), upv.data_ptr(), upv.stride(0), N, h, w, u["cin"], c, self.dt, s)
             name = f"dec{lvl}"
+            head_norm = train and FUSE_HEAD_BN and lvl == 1          # dec1.3: normalised by the head while loading
             self._stage_fwd(self.stages[(name, 0)], self.cat[lvl], self.a0[name], train)
-            self._stage_fwd(self.stages[(name, 3)], self.a0[name], self.a3[name], train)
+            self._stage_fwd(self.stages[(name, 3)], self.a0[name], self.a3[name], train, apply=not head_norm)
             hin = self.a3[name]
         probs = torch.empty(N, self.oc, self.H, self.W, device=self.device, dtype=torch.float32)
         oc = self.model.out_conv
-        call("unetdc_head_fwd", hin.data_ptr(), hin.stride(0), oc.weight.data_ptr(), oc.bias.data_ptr(),
-             probs.data_ptr(), N, self.H, self.W, 64, self.oc, self.dt, s)
+        if train and FUSE_HEAD_BN:
+            last = self.stages[("dec1", 3)]
+            call("unetdc_head_fwd_bn", last.y.data_ptr(), last.y.stride(0), last.scale.data_ptr(), last.shift.data_ptr(),
+                 oc.weight.data_ptr(), oc.bias.data_ptr(), probs.data_ptr(), N, self.H, self.W, 64, self.oc, self.dt, s)
+            hin = None                                              # no activation tensor: the backward recomputes it from y
+        else:
+            call("unetdc_head_fwd", hin.data_ptr(), hin.stride(0), oc.weight.data_ptr(), oc.bias.data_ptr(),
+                 probs.data_ptr(), N, self.H, self.W, 64, self.oc, self.dt, s)
         self.head_in = hin
         if self._nbt:
             torch._foreach_add_(self._nbt, 1)                  # nn.BatchNorm2d's num_batches_tracked += 1, one launch
@@ -571,8 +584,8 @@ class UNetEngine:
         da = g[("da", 0)]
         last = self.stages[("dec1", 3)]                  # its activated output feeds out_conv
         if FUSE_BN_BWD:                                  # da's BatchNorm-backward sums come out of the same pass
-            call("unetdc_head_bwd_bnstats", dprobs.data_ptr(), probs.data_ptr(), self.head_in.data_ptr(),
-                 self.head_in.stride(0), oc.weight.data_ptr(), da.data_ptr(), da.stride(0),
+            call("unetdc_head_bwd_bnstats", dprobs.data_ptr(), probs.data_ptr(), _ptr(self.head_in),
+                 self.head_in.stride(0) if self.head_in is not None else 64, oc.weight.data_ptr(), da.data_ptr(), da.stride(0),
                  self._gview(flat, oc.weight).data_ptr(), self._gview(flat, oc.bias).data_ptr(), ws, wsb,
                  *self._bnstats_args(last), N, self.H, self.W, 64, self.oc, self.dt, s)
             last.bwd_nparts = self._np.value
