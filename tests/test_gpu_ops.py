@@ -393,7 +393,11 @@ def test_head_bwd_fused_bn_backward_sums(dtype, shape):
     parts = torch.full(((rows + 64) * 3 * c,), float("nan"), device="cuda")
     dv = [t.cuda() for t in (scale, shift, mean, rstd)]
     npar = ctypes.c_int(0)
-    # normalise-on-load forward: the head fed from the raw conv output == the head fed from the stored activation, bit for bit
+    # normalise-on-load forward: the head fed from the raw conv output == the head fed from the activation the stand-alone
+    # pass stores (unetdc_bn_relu_apply: the same fused multiply-add and rounding), bit for bit
+    av = G.empty_nhwc(n * h * w, c, dtype)
+    call("unetdc_bn_relu_apply", yv.data_ptr(), yv.stride(0), dv[0].data_ptr(), dv[1].data_ptr(), av.data_ptr(), av.stride(0),
+         None, 0, n, h, w, c, G.DT[dtype], G.stream())
     bd2 = (torch.randn(oc, generator=g) * 0.1).cuda()
     p_a, p_y = (torch.full((n, oc, h, w), float("nan"), device="cuda") for _ in range(2))
     call("unetdc_head_fwd", av.data_ptr(), av.stride(0), wd2.data_ptr(), bd2.data_ptr(), p_a.data_ptr(), n, h, w, c, oc,
