@@ -61,14 +61,14 @@ def test_host_only_queries_and_error_reporting(lib):
     assert rc == -1 and b"geometry" in lib.unetdc_last_error()
 
 
-def test_convolution_kernels_carry_no_packed_fp32(lib):
-    """Build guard: the packed-fp32 (SLP-vectorised) build of the fused BatchNorm-backward epilogue was not
-    run-to-run deterministic on MI355X; the library is built with -fno-slp-vectorize.  Disassemble the gfx950 code
-    objects of the library and fail if a toolchain or flag change brings v_pk_{add,mul,fma}_f32 back into any
-    convolution / BatchNorm kernel (the GPU-side determinism test only proves that one build is stable)."""
+def test_no_kernel_carries_packed_fp32(lib):
+    """Build guard (widened in round 3 to EVERY kernel of the library): the packed-fp32 (SLP-vectorised) build
+    of the fused BatchNorm-backward epilogue was not run-to-run deterministic on MI355X and the cause is not identified
+    (DESIGN.md section 7); the library is built with -fno-slp-vectorize.  Disassemble the gfx950 code objects of the library
+    and fail if a toolchain or flag change brings v_pk_{add,mul,fma}_f32 back anywhere -- convolutions, BatchNorm, head,
+    optimizer, elementwise, first layer (the GPU-side determinism test only proves that one build is stable)."""
     from unet_dc_segmentation_amd import build
     rep = build.packed_f32_report()
-    guarded = {k: v for k, v in rep.items() if re.search(r"igemm|wgrad_(dma|ring|fused|rect)|bn_|head_|convT", k)}
-    assert len(guarded) >= 20, sorted(rep)
-    bad = {k: v for k, v in guarded.items() if v}
+    assert len(rep) >= 100 and sum(1 for k in rep if re.search(r"igemm|wgrad_(dma|ring|fused|rect)|bn_|head_", k)) >= 20, sorted(rep)
+    bad = {k: v for k, v in rep.items() if v}
     assert not bad, bad

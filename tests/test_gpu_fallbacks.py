@@ -1,6 +1,5 @@
 """The A/B switches select older or alternative kernels inside the same library (first-generation register-staged
-implicit GEMM and weight gradient, per-tap LDS-DMA kernels, 32x32x16 MFMA shape, three-segment tap-fused wgrad,
-VALU first layer).  They are also the fallbacks for shapes the fast kernels do not take (>= 2 GiB tensors, ragged
+implicit GEMM and weight gradient, halo-patch convolutions, three-segment tap-fused wgrad, VALU first layer).  They are also the fallbacks for shapes the fast kernels do not take (>= 2 GiB tensors, ragged
 pixel counts), so the operator parity tests are re-run under each switch set -- in a child process, because the
 switches are read once per process."""
 import os
@@ -14,28 +13,29 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SWITCH_SETS = {
+    # the >= 2 GiB / ragged-shape fallbacks: first-generation register-staged implicit GEMM and weight gradient, VALU first layer
     "first_generation": {"UNETDC_IGEMM": "legacy", "UNETDC_WGRAD": "legacy", "UNETDC_FIRST": "valu"},
-    "per_tap_dma_32x32": {"UNETDC_IGEMM": "dma", "UNETDC_WGRAD": "dma", "UNETDC_MFMA16": "0"},
-    "fused_without_ring_unfused_epilogues": {"UNETDC_WGRAD_RING": "0", "UNETDC_MFMA16": "0", "UNETDC_FUSE_BNBWD": "0",
-                                             "UNETDC_FUSE_COLSUM": "0", "UNETDC_FUSED_LOSS": "0"},
-    # round-2 kernels off: halo-patch / per-tap convolutions instead of the persistent lattice kernel, quadrant ring and
-    # per-tap weight gradients instead of the tap-split ring and the valid-rectangle kernel, per-pixel first-layer wgrad
+    # every fusion off: stand-alone BatchNorm-backward reduction, column sums, loss; three-segment weight gradient
+    "unfused_epilogues": {"UNETDC_WGRAD_RING": "0", "UNETDC_FUSE_BNBWD": "0", "UNETDC_FUSE_COLSUM": "0", "UNETDC_FUSED_LOSS": "0"},
+    # round-2 kernels off: halo-patch / per-tap convolutions instead of the persistent lattice kernel (the halo-patch kernel
+    # is also the fp32 path), quadrant ring and per-tap weight gradients instead of the tap-split ring and the valid-rectangle
+    # kernel, per-pixel first-layer wgrad
     "round1_kernels": {"UNETDC_LATTICE": "0", "UNETDC_WGRAD_SPLIT": "0", "UNETDC_WGRAD_RECT": "0", "UNETDC_FIRST_ROWS": "0"},
-    # the first lattice form (8 waves of 64 x 64, two patch buffers, 3-stage ring) instead of the wide-wave one
-    "lattice_8_waves": {"UNETDC_LAT_WIDE": "0"},
+    # round-3 choices off: 32x32x16 MFMA shape in the tap-split weight gradient, row-major blocks for d % 16 == 0
+    "round3_ab": {"UNETDC_WGRAD_M16": "0", "UNETDC_QUAD": "0"},
 }
 
 
 @pytest.mark.parametrize("name", sorted(SWITCH_SETS))
 def test_operator_parity_under_switches(name):
     env = dict(os.environ, **SWITCH_SETS[name])
-    sel = "conv3x3_fwd_dgrad_wgrad or wgrad_tap_fused or first_conv or conv_transpose or fused_bn_backward_statistics"
-    if name == "fused_without_ring_unfused_epilogues":
+    sel = "conv3x3_fwd_dgrad_wgrad or first_conv or conv_transpose or fused_bn_backward_statistics"
+    if name == "unfused_epilogues":
         sel = "wgrad_tap_fused or conv3x3_fwd_dgrad_wgrad"
-    if name == "lattice_8_waves":                          # a bf16-only kernel choice: the fp32 cases would repeat the default run
-        sel = "(conv3x3_fwd_dgrad_wgrad or fused_bn_backward_statistics) and not f32"
     if name == "round1_kernels":
-        sel = "(" + sel + ") and not f32"
+        sel = "(" + sel + " or wgrad_tap_fused) and not f32"
+    if name == "round3_ab":                                # bf16-only kernel choices
+        sel = "(conv3x3_fwd_dgrad_wgrad or wgrad_tap_fused) and not f32"
     cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_ops.py"), "-m", "gpu", "-x", "-q",
            "-k", sel, "-p", "no:cacheprovider"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
@@ -60,7 +60,7 @@ focal_dice_loss(m(x), t, alpha=1.0, gamma=2.0, ratio=0.3).backward()
 torch.save({k: p.grad.cpu() for k, p in m.named_parameters()}, sys.argv[1])
 ''' % ROOT
     outs = []
-    for i, extra in enumerate(({}, SWITCH_SETS["fused_without_ring_unfused_epilogues"], {"UNETDC_FUSE_POOL_SKIP": "1"})):
+    for i, extra in enumerate(({}, dict(SWITCH_SETS["unfused_epilogues"], UNETDC_FUSE_HEAD_BN="0"), {"UNETDC_FUSE_POOL_SKIP": "1"})):
         path = os.path.join("/tmp", f"unetdc_fallback_grads_{os.getpid()}_{i}.pt")
         r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **extra), cwd=ROOT,
                            capture_output=True, text=True, timeout=600)

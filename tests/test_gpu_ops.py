@@ -5,6 +5,8 @@ Tolerances: fp32 path -- exact-fp32 MFMA, only the summation order differs: rel-
 bf16 path -- inputs are pre-rounded to bf16 so both sides see identical operands; the error
 left is fp32-accumulate order + one bf16 rounding of the output (2^-9): rel-L2 <= 6e-3.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -83,7 +85,8 @@ def test_conv3x3_fwd_dgrad_wgrad(dtype, case):
     np.testing.assert_allclose(stc[1].numpy(), (yq * yq).sum(dim=(0, 2, 3)).numpy(), rtol=1e-4, atol=1e-2)
     # rows that carry data (the persistent kernel writes one row per workgroup and zeros into the rest of the bound)
     live = _lib.load().unetdc_last_stats_rows()
-    if dtype == "bf16" and d % 16 == 0 and h % 16 == 0 and w % 16 == 0:
+    default_route = not any(k in os.environ for k in ("UNETDC_IGEMM", "UNETDC_QUAD"))   # (test_gpu_fallbacks.py re-runs this file under switches)
+    if default_route and dtype == "bf16" and d % 16 == 0 and h % 16 == 0 and w % 16 == 0:
         assert _lib.load().unetdc_last_kernel().decode().endswith("blocks16x16")        # routed to the block-order form
     assert 1 <= live <= rows
     sta = st.cpu()[: rows * 2 * cout].reshape(rows, 2, cout)

@@ -116,9 +116,6 @@ template <> struct PairRaw<float> {
 
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
-// streaming forms (`nt`): for bytes that are read once and not again before they would be evicted anyway
-__device__ __forceinline__ u32x4 ld16_nt(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
-__device__ __forceinline__ u32x4 ld16_sel(const void* p, bool nt) { return nt ? ld16_nt(p) : ld16(p); }
 
 // XCD-aware remap of a linear workgroup id: blocks b and b+8 share an XCD (observed round-robin
 // placement; speed only, never correctness), so give each XCD one contiguous chunk of the tile

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const ApplyParams p)
     }
     if (!POOL) {
       float v[EPC];
-      Chunk<T>::unpack(ld16_sel(yg + q * p.ldy + c0, p.nt), v);
+      Chunk<T>::unpack(ld16(yg + q * p.ldy + c0), v);
       if (p.scale) {
 #pragma unroll
         for (int e = 0; e < EPC; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const ApplyParams p)
       for (int k = 0; k < 4; ++k) {
         const long pix = ((long)n * p.H + 2 * yq + (k >> 1)) * p.W + 2 * xq + (k & 1);
         float v[EPC];
-        Chunk<T>::unpack(ld16_sel(yg + pix * p.ldy + c0, p.nt), v);
+        Chunk<T>::unpack(ld16(yg + pix * p.ldy + c0), v);
         if (p.scale) {
 #pragma unroll
           for (int e = 0; e < EPC; ++e) v[e] = round_through<T>(fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f));
@@ -206,8 +206,8 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdParams p) {
     for (long q = (long)blockIdx.x * plane + pl; q < Q; q += (long)gridDim.x * plane) {
       if (!POOL) {
         float yv[EPC], g[EPC];
-        Chunk<T>::unpack(ld16_sel(yg + q * p.ldy + c0, APPLY && p.nt), yv);
-        Chunk<T>::unpack(ld16_sel(sg + q * p.lds + c0, APPLY && p.nt), g);
+        Chunk<T>::unpack(ld16(yg + q * p.ldy + c0), yv);
+        Chunk<T>::unpack(ld16(sg + q * p.lds + c0), g);
         float out[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
@@ -227,9 +227,9 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdParams p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           pix[k] = ((long)n * p.H + 2 * yq + (k >> 1)) * p.W + 2 * xq + (k & 1);
-          Chunk<T>::unpack(ld16_sel(yg + pix[k] * p.ldy + c0, APPLY && p.nt), yv[k]);
+          Chunk<T>::unpack(ld16(yg + pix[k] * p.ldy + c0), yv[k]);
         }
-        Chunk<T>::unpack(ld16_sel(dpg + q * p.ldp + c0, APPLY && p.nt), dp);
+        Chunk<T>::unpack(ld16(dpg + q * p.ldp + c0), dp);
         int arg[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdParams p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float g[EPC], out[EPC];
-          if (sg) Chunk<T>::unpack(ld16_sel(sg + pix[k] * p.lds + c0, APPLY && p.nt), g);
+          if (sg) Chunk<T>::unpack(ld16(sg + pix[k] * p.lds + c0), g);
 #pragma unroll
           for (int e = 0; e < EPC; ++e) {
             const float gin = (sg ? g[e] : 0.f) + (arg[e] == k ? dp[e] : 0.f);
@@ -651,15 +651,8 @@ int launch_bn_eval_affine(const float* gamma, const float* beta, const float* rm
   return check_launch("bn_eval_affine_kernel");
 }
 
-static int nt_loads() {
-  static int v = -1;                              // UNETDC_NT=1: streaming (nt) loads in the BatchNorm passes (A/B measurements)
-  if (v < 0) { const char* e = getenv("UNETDC_NT"); v = (e && e[0] == '1') ? 1 : 0; }
-  return v;
-}
-
 int launch_apply(ApplyParams& p, int dtype, hipStream_t stream) {
   const int epc = dtype == UNETDC_BF16 ? 8 : 4;
-  p.nt = nt_loads();
   UNETDC_REQUIRE(dtype == UNETDC_F32 || dtype == UNETDC_BF16, "bn_relu_apply: bad dtype %d", dtype);
   UNETDC_REQUIRE(p.y, "bn_relu_apply: null input");
   UNETDC_REQUIRE(p.C % epc == 0 && p.ldy % epc == 0, "bn_relu_apply: C/ld not chunk aligned");
@@ -740,7 +733,6 @@ int launch_bn_bwd(BnBwdParams& p, const float* gamma, float* dgamma, float* dbet
   UNETDC_REQUIRE(p.scale && p.shift && p.mean && p.rstd && gamma && dgamma && dbeta && workspace, "bn_bwd: null pointer");
   UNETDC_REQUIRE(p.C % epc == 0 && p.ldy % epc == 0 && p.lddy % epc == 0, "bn_bwd: C/ld not chunk aligned");
   const bool pool = p.dpool != nullptr;
-  p.nt = nt_loads();
   if (pool) UNETDC_REQUIRE(p.H % 2 == 0 && p.W % 2 == 0 && p.ldp % epc == 0, "bn_bwd: pooling needs even H, W");
   if (!pool) UNETDC_REQUIRE(p.dskip != nullptr, "bn_bwd: gradient missing");
   if (p.dskip) UNETDC_REQUIRE(p.lds % epc == 0, "bn_bwd: lds not chunk aligned");

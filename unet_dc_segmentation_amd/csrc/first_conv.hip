@@ -155,7 +155,10 @@ __global__ __launch_bounds__(256) void first_conv_wgrad_kernel(const FirstWgradP
   for (int i = tid; i < 9 * p.Cout; i += 256) {
     const int t = i / p.Cout, co = i - t * p.Cout, gg = co / 8, e = co % 8;
     float s = 0.f;
-    for (int w2 = 0; w2 < 4; ++w2) s += red[(w2 * G + gg) * 72 + t * 8 + e];
+    for (int w2 = 0; w2 < 4; ++w2) {
+      s += red[(w2 * G + gg) * 72 + t * 8 + e];
+      asm volatile("" : "+v"(s));     // opaque: the loop is unrolled by two and the two sums would pair into v_pk_add_f32 (no packed fp32 in this library, build.py)
+    }
     p.part[(((long)blockIdx.x * p.Cin + ci) * 9 + t) * p.Cout + co] = s;
   }
 }
@@ -235,7 +238,10 @@ __global__ __launch_bounds__(256) void first_wgrad_rows_kernel(const FirstWgradP
   for (int i = tid; i < 9 * p.Cout; i += 256) {
     const int t = i / p.Cout, co = i - t * p.Cout, gg = co / 8, e = co % 8;
     float s = 0.f;
-    for (int w2 = 0; w2 < 4; ++w2) s += red[(w2 * G + gg) * 72 + t * 8 + e];
+    for (int w2 = 0; w2 < 4; ++w2) {
+      s += red[(w2 * G + gg) * 72 + t * 8 + e];
+      asm volatile("" : "+v"(s));     // opaque: the loop is unrolled by two and the two sums would pair into v_pk_add_f32 (no packed fp32 in this library, build.py)
+    }
     p.part[(((long)blockIdx.x * p.Cin + ci) * 9 + t) * p.Cout + co] = s;
   }
 }

@@ -285,9 +285,7 @@ static int launch_dma16_cfg(IgemmParams& p, hipStream_t stream) {
 }
 
 bool igemm_dma16_supported(const IgemmParams& p, int dtype) {
-  static int off = -1;                                   // UNETDC_MFMA16=0: the 32x32x16 kernels (A/B measurements)
-  if (off < 0) { const char* e = getenv("UNETDC_MFMA16"); off = (e && e[0] == '0') ? 1 : 0; }
-  if (off || dtype != UNETDC_BF16) return false;
+  if (dtype != UNETDC_BF16) return false;
   if (p.M % 16 != 0) return false;
   if (p.mode == MODE_SHUFFLE && p.Wo % 16 != 0) return false;
   return true;

@@ -377,9 +377,7 @@ bool igemm_halo_supported(const IgemmParams& p, int dtype) {
   const int d = p.offy[8];                       // taps are (ky-1)*d, (kx-1)*d
   if (d < 1 || d > 2) return false;
   if (p.offx[8] != d || p.offy[0] != -d || p.offx[0] != -d) return false;
-  static int wide = -1;                          // UNETDC_HALO_WIDE=1: also C_out = 256 / 512 (n-blocks of 128 over one patch each)
-  if (wide < 0) { const char* e = getenv("UNETDC_HALO_WIDE"); wide = (e && e[0] == '1') ? 1 : 0; }
-  if (!(p.Cout == 64 || p.Cout == 128 || (wide && p.Cout % 128 == 0 && p.Cout <= 512))) return false;
+  if (!(p.Cout == 64 || p.Cout == 128)) return false;
   if (p.Ho % TH != 0 || p.Wo % TW != 0) return false;
   if ((long)p.M < 256L * 512) return false;      // small maps: not worth a patch per tile
   const long es = dtype == UNETDC_BF16 ? 2 : 4;
@@ -388,11 +386,7 @@ bool igemm_halo_supported(const IgemmParams& p, int dtype) {
   return xbytes < (1L << 31) && obytes < (1L << 32) && ybytes < (1L << 32);
 }
 
-static bool halo_mfma16() {
-  static int off = -1;                                   // UNETDC_MFMA16=0: 32x32x16 kernels (A/B measurements)
-  if (off < 0) { const char* e = getenv("UNETDC_MFMA16"); off = (e && e[0] == '0') ? 1 : 0; }
-  return !off;
-}
+static bool halo_mfma16() { return true; }            // bf16: the 16x16x32 form (the A/B against 32x32x16 was settled in round 1)
 
 template <typename T, int WN>
 static int launch_halo_cfg(IgemmParams& p, int d, hipStream_t stream) {

@@ -863,14 +863,10 @@ int launch_igemm_lattice(IgemmParams& p, hipStream_t stream) {
   const int nimg = (int)((long)p.M / ((long)p.Ho * p.Wo));
   q.mtiles = nimg * q.tiles_per_img;              // = M / 256
   const bool wide = p.Cout % 128 == 0;
-  static int wide_wave = -1;                      // UNETDC_LAT_WIDE=0: the 8-wave 64 x 64-per-wave form for 128-channel n-blocks (A/B)
-  if (wide_wave < 0) { const char* e = getenv("UNETDC_LAT_WIDE"); wide_wave = (e && e[0] == '0') ? 0 : 1; }
-  // 4 waves x (64 pixels x 128 channels), two workgroups per CU: the statistics and folded-BatchNorm forms (the plain-store
-  // instantiation spills 36 registers -- its reloads would drain the VM counter in front of the hand-placed DMAs -- and the
-  // fused BatchNorm-backward epilogue does not fit next to 128 accumulators: both keep the 8-wave form)
-  static int wide_bnbwd = -1;                     // UNETDC_LAT_WIDE_BNBWD=0: fused BatchNorm-backward epilogue on the 8-wave form (A/B)
-  if (wide_bnbwd < 0) { const char* e = getenv("UNETDC_LAT_WIDE_BNBWD"); wide_bnbwd = (e && e[0] == '0') ? 0 : 1; }
-  const bool ww = wide && wide_wave && (p.mode == MODE_STATS || p.mode == MODE_AFFINE_RELU || (p.mode == MODE_BNBWD && wide_bnbwd));
+  // 4 waves x (64 pixels x 128 channels), two workgroups per CU: the statistics, folded-BatchNorm and fused-BatchNorm-backward
+  // forms; the plain-store instantiation spills 36 registers -- its reloads would drain the VM counter in front of the
+  // hand-placed DMAs -- and keeps the 8-wave form (4 x 2 waves of 64 x 64, two patch buffers)
+  const bool ww = wide && (p.mode == MODE_STATS || p.mode == MODE_AFFINE_RELU || p.mode == MODE_BNBWD);
   const int wgs = (wide && !ww) ? 1 : 2;          // workgroups per CU of the configurations
   q.nblocks = p.Cout / (wide ? 128 : 64);
   q.items = q.mtiles * q.nblocks;

@@ -84,7 +84,6 @@ struct ApplyParams {
   const void* y; void* a; void* pooled;
   const float* scale; const float* shift;
   int N, H, W, C, ldy, lda, ldp;
-  int nt;                  // 1: streaming (nt) loads of y
 };
 struct BnBwdParams {
   const void* dskip; const void* dpool; const void* y; void* dy;
@@ -92,7 +91,6 @@ struct BnBwdParams {
   const float* k1; const float* k2; const float* k3;
   float* parts;            // [gridDim.x][3][C]
   int N, H, W, C, lds, ldp, ldy, lddy;
-  int nt;                  // 1: streaming (nt) loads of y and of the incoming gradient in the apply pass (their last use)
 };
 struct HeadParams {
   const void* a; const float* w; const float* b; float* probs;

@@ -60,6 +60,32 @@ template <int TW> struct Frag<bf16_t, TW> {
   }
 };
 
+// 16x16x32 operands from a [pixel][64 channels] bf16 image (128-byte rows): a fragment = 16 channels x 32 pixel rows, lane l
+// holds channel cbase + (l & 15), pixels krow0 + 8 (l >> 4) + j in element j -- the A and the B map of
+// v_mfma_f32_16x16x32_bf16 alike.  Two ds_read_b64_tr_b16 per fragment: block jj of lane group G = pixel rows
+// krow0 + 8 G + 4 jj + (0..3), 16 channels.  The two groups of a 32-lane half read rows 8 apart in the SAME columns, and the
+// four rows of a block are consecutive: the image is swizzled in 16-byte chunks (through the DMA source addresses),
+//   physical chunk = logical chunk ^ (((row >> 1) & 1) << 2) ^ (((row >> 3) & 1) << 1)
+// so that the four rows of a block sit in four different 64-byte windows of the 256-byte bank row and the blocks of the two
+// groups in different 32-byte halves of them -- conflict-free at every row offset (tap shifts move krow0 by kx * d).
+struct Frag16 {
+  static constexpr int RB = 128;
+  __device__ static __forceinline__ int key(int row) { return (((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 1); }
+  // logical 16-byte chunk that must be fetched into physical chunk `pc` of pixel row `row`
+  __device__ static __forceinline__ int src_chunk(int row, int pc) { return pc ^ key(row); }
+  __device__ static __forceinline__ int rd_off(int lane, int cbase, int krow0, int jj) {
+    const int i = lane & 15, G = lane >> 4, q = i >> 2, pp = i & 3;
+    const int krow = krow0 + 8 * G + 4 * jj + q;
+    const int byte = (cbase + 4 * pp) * 2;
+    return krow * RB + (((byte >> 4) ^ key(krow)) << 4) + (byte & 15);
+  }
+  __device__ static __forceinline__ bf16x8 frag_at(const unsigned char* s, int off0, int off1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(s + off0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(s + off1));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  }
+};
+
 template <int TW> struct Frag<float, TW> {
   static constexpr int RB = TW * 256;
   __device__ static __forceinline__ int wr_off(int row, int ch) { return row * RB + ch * 16; }

@@ -415,7 +415,192 @@ __device__ __forceinline__ void ring_split_step(f32x16 (&acc)[5][2], const unsig
 #endif
 }
 
-template <int PF, int TG>
+// ------------------------------------------------------------------------------------------------
+// The same wave roles on v_mfma_f32_16x16x32_bf16 (M16 = true, the default; UNETDC_WGRAD_M16=0 selects the 32x32x16 form).
+// These kernels are power bound like the convolutions (igemm_dma16.hip): MI355X_MICROARCH.md measures 1.12-1.15x the FLOP/s
+// for the 16x16x32 shape at equal cycles per FLOP with operands re-read from LDS.  LDS traffic per FLOP is unchanged (a
+// fragment is still two transposed 8-byte reads per lane for 512 multiply-adds per lane), the accumulators are the same
+// 160 registers: a wave owns 64 co x 32 ci = 4 x 2 tiles of 16 x 16 per tap slot.  A row of 64 pixels is two k32 steps;
+// tg 0 takes taps 0..4 on the first and 0..3 on the second, tg 1 taps 5..8 and 4..8 (tap 4 split over the two, joined through
+// LDS at the end as before).  Image swizzle and fragment addresses: wgrad_frag.h, Frag16.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int s16_k32(int tg, int i) { return tg == 0 ? (i < 5 ? 0 : 1) : (i < 4 ? 0 : 1); }
+__host__ __device__ constexpr int s16_tap(int tg, int i) { return tg == 0 ? (i < 5 ? i : i - 5) : (i < 4 ? 5 + i : i); }
+
+struct Split16Offs {       // per-lane byte offsets of the transposed reads at k32 step 0 (step 1: + 32 rows = 4096 bytes)
+  int dy[4][2];            // [co tile][block jj]
+  int x[3][2][2];          // [kx][ci tile][block jj], pixel rows shifted by kx * d
+};
+
+template <bool M16> struct SplitAcc;
+template <> struct SplitAcc<false> { f32x16 a[5][2]; };
+template <> struct SplitAcc<true> { f32x4 a[5][4][2]; };
+
+__device__ __forceinline__ void split_zero(SplitAcc<false>& A) {
+#pragma unroll
+  for (int t = 0; t < 5; ++t)
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) A.a[t][ih][e] = 0.f;
+}
+__device__ __forceinline__ void split_zero(SplitAcc<true>& A) {
+#pragma unroll
+  for (int t = 0; t < 5; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) A.a[t][c][j][e] = 0.f;
+}
+
+template <int TG>
+__device__ __forceinline__ void ring_split_step16(f32x4 (&acc)[5][4][2], const unsigned char* sdy, const unsigned char* sx0,
+                                                  const unsigned char* sx1, const unsigned char* sx2, const Split16Offs& o) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NI = 9;
+  // A (dY) fragments: ONE set of four, refilled in place for the second k32 step -- each one right behind the two MFMAs of
+  // the first step's last item that read it (an in-order wave: an issued MFMA has its operands) -- 16 registers instead of
+  // 32: with a double set the kernel needs more than the 256 registers two workgroups per CU leave a wave.
+  // B (X) fragments: two sets of two, item i + 1 loaded in front of the MFMAs of item i.
+  bf16x8 fa[4], fb[2][2];
+  auto load_a1 = [&](int k32, int c) { fa[c] = Frag16::frag_at(sdy + k32 * 4096, o.dy[c][0], o.dy[c][1]); };
+  auto load_b = [&](int i) {
+    const int k32 = s16_k32(TG, i), t = s16_tap(TG, i), ky = t / 3, kx = t - 3 * ky;
+    const unsigned char* sx = (ky == 0 ? sx0 : (ky == 1 ? sx1 : sx2)) + k32 * 4096;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fb[i & 1][j] = Frag16::frag_at(sx, o.x[kx][j][0], o.x[kx][j][1]);
+  };
+#pragma unroll
+  for (int c = 0; c < 4; ++c) load_a1(0, c);
+  load_b(0);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int k32 = s16_k32(TG, i);
+    const bool turn = i + 1 < NI && s16_k32(TG, i + 1) != k32;      // last item of the first k32 step
+    if (i + 1 < NI) load_b(i + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const int slot = s16_tap(TG, i) - (TG == 0 ? 0 : 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[slot][c][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[c], fb[i & 1][j], acc[slot][c][j], 0, 0, 0);
+      if (turn) {
+        __builtin_amdgcn_sched_barrier(0);
+        load_a1(k32 + 1, c);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#endif
+}
+
+// one image row of the strip: both forms behind one name
+template <int TG>
+__device__ __forceinline__ void split_step(SplitAcc<false>& A, const unsigned char* sdy, const unsigned char* sx0,
+                                           const unsigned char* sx1, const unsigned char* sx2, int lane, int qj, int d,
+                                           const Split16Offs&) {
+  ring_split_step<TG>(A.a, sdy, sx0, sx1, sx2, lane, qj, d);
+}
+template <int TG>
+__device__ __forceinline__ void split_step(SplitAcc<true>& A, const unsigned char* sdy, const unsigned char* sx0,
+                                           const unsigned char* sx1, const unsigned char* sx2, int, int, int,
+                                           const Split16Offs& o) {
+  ring_split_step16<TG>(A.a, sdy, sx0, sx1, sx2, o);
+}
+
+// tap 4: tg 1's half (slot 0) joins tg 0's (slot 4) through LDS (fixed order), then the partial slab part[unit][t][i][j]:
+// tg 0 stores taps 0..4, tg 1 taps 5..8.  The caller guarantees that every DMA has landed and every fragment has been read.
+__device__ __forceinline__ void split_finish(SplitAcc<false>& A, unsigned char* smem, const WgradFusedParams& p, int unit,
+                                             int i0, int j0, int qj, int tg, int lane) {
+  float* xch = reinterpret_cast<float*>(smem);
+  __syncthreads();
+  if (tg == 1) {
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) xch[((qj * 2 + ih) * 16 + reg) * 64 + lane] = A.a[0][ih][reg];
+  }
+  __syncthreads();
+  if (tg == 0) {
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) A.a[4][ih][reg] += xch[((qj * 2 + ih) * 16 + reg) * 64 + lane];
+  }
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int sl = 0; sl < 5; ++sl) {
+    if (tg == 1 && sl == 0) continue;
+    const int t = sl + (tg == 0 ? 0 : 4);
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih) {
+      float* slab = p.part + ((long)unit * 9 + t) * p.CI * p.CJ + (long)(i0 + ih * 32 + 4 * h) * p.CJ + j0 + qj * 32 + r;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) slab[(long)((reg & 3) + 8 * (reg >> 2)) * p.CJ] = A.a[sl][ih][reg];
+    }
+  }
+}
+__device__ __forceinline__ void split_finish(SplitAcc<true>& A, unsigned char* smem, const WgradFusedParams& p, int unit,
+                                             int i0, int j0, int qj, int tg, int lane) {
+  float* xch = reinterpret_cast<float*>(smem);             // [qj][co tile][ci tile][v][lane]: 16 KB
+  __syncthreads();
+  if (tg == 1) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) xch[(((qj * 4 + c) * 2 + j) * 4 + v) * 64 + lane] = A.a[0][c][j][v];
+  }
+  __syncthreads();
+  if (tg == 0) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) A.a[4][c][j][v] += xch[(((qj * 4 + c) * 2 + j) * 4 + v) * 64 + lane];
+  }
+  // accumulator element v of a 16 x 16 tile: row (co) 4 * (lane >> 4) + v, column (ci) lane & 15
+  const int col = lane & 15, rq = lane >> 4;
+#pragma unroll
+  for (int sl = 0; sl < 5; ++sl) {
+    if (tg == 1 && sl == 0) continue;
+    const int t = sl + (tg == 0 ? 0 : 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float* slab = p.part + ((long)unit * 9 + t) * p.CI * p.CJ + (long)(i0 + 16 * c + 4 * rq) * p.CJ + j0 + qj * 32 + 16 * j + col;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) slab[(long)v * p.CJ] = A.a[sl][c][j][v];
+      }
+  }
+}
+
+template <bool M16>
+__device__ __forceinline__ Split16Offs split_offsets(int lane, int qj, int d) {
+  Split16Offs o;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) o.dy[c][jj] = M16 ? Frag16::rd_off(lane, 16 * c, 0, jj) : 0;
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) o.x[kx][j][jj] = M16 ? Frag16::rd_off(lane, qj * 32 + 16 * j, kx * d, jj) : 0;
+  return o;
+}
+template <bool M16> __device__ __forceinline__ int split_src_chunk(int row, int pc) {
+  return M16 ? Frag16::src_chunk(row, pc) : Frag<bf16_t, 1>::src_chunk(row, pc);
+}
+
+template <int PF, int TG, bool M16>
 __device__ __forceinline__ void ring_split_body(const WgradFusedParams& p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using T = bf16_t;
@@ -467,11 +652,11 @@ __device__ __forceinline__ void ring_split_body(const WgradFusedParams& p) {
     const int gi = wave + 4 * q;
     if (gi < DYI) {
       const int row = gi * RPI + sub;
-      colb[q] = (unsigned)(((x0 + row) * p.lddy + i0) * ES + Frag<T, 1>::src_chunk(row, pc) * 16);
+      colb[q] = (unsigned)(((x0 + row) * p.lddy + i0) * ES + split_src_chunk<M16>(row, pc) * 16);
     } else if (gi < GI) {
       const int row = (gi - DYI) * RPI + sub;
       const int gx = x0 - d + row;
-      colb[q] = ((unsigned)gx < (unsigned)p.W) ? (unsigned)((gx * p.ldx + j0) * ES + Frag<T, 1>::src_chunk(row, pc) * 16) : FOOB;
+      colb[q] = ((unsigned)gx < (unsigned)p.W) ? (unsigned)((gx * p.ldx + j0) * ES + split_src_chunk<M16>(row, pc) * 16) : FOOB;
     } else {
       colb[q] = FOOB;
     }
@@ -499,13 +684,9 @@ __device__ __forceinline__ void ring_split_body(const WgradFusedParams& p) {
     }
   };
 
-  f32x16 acc[5][2];
-#pragma unroll
-  for (int t = 0; t < 5; ++t)
-#pragma unroll
-    for (int ih = 0; ih < 2; ++ih)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[t][ih][e] = 0.f;
+  SplitAcc<M16> acc;
+  split_zero(acc);
+  const Split16Offs offs = split_offsets<M16>(lane, qj, d);
 
   for (int img = 0; img < ipu && n0 + img < p.N; ++img) {
   n = n0 + img;
@@ -537,7 +718,7 @@ __device__ __forceinline__ void ring_split_body(const WgradFusedParams& p) {
       gslot_x = (gslot_x + 1 == R) ? 0 : gslot_x + 1;
     }
     const unsigned char* sdyp = smem + sdy * DYB;
-    ring_split_step<TG>(acc, sdyp, xring + sl0 * XB, xring + sl1 * XB, xring + sl2 * XB, lane, qj, d);
+    split_step<TG>(acc, sdyp, xring + sl0 * XB, xring + sl1 * XB, xring + sl2 * XB, lane, qj, d, offs);
     sl0 = (sl0 + 1 == R) ? 0 : sl0 + 1;
     sl1 = (sl1 + 1 == R) ? 0 : sl1 + 1;
     sl2 = (sl2 + 1 == R) ? 0 : sl2 + 1;
@@ -545,48 +726,20 @@ __device__ __forceinline__ void ring_split_body(const WgradFusedParams& p) {
   }
   }                                                      // images of this unit
 
-  // ---- tap 4: tg 1's half (slot 0) joins tg 0's (slot 4) through LDS; every DMA has landed (vmcnt(0) on the last step) ----
-  float* xch = reinterpret_cast<float*>(smem);
-  __syncthreads();
-  if (tg == 1) {
-#pragma unroll
-    for (int ih = 0; ih < 2; ++ih)
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) xch[((qj * 2 + ih) * 16 + reg) * 64 + lane] = acc[0][ih][reg];
-  }
-  __syncthreads();
-  if (tg == 0) {
-#pragma unroll
-    for (int ih = 0; ih < 2; ++ih)
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) acc[4][ih][reg] += xch[((qj * 2 + ih) * 16 + reg) * 64 + lane];
-  }
-
-  // ---- partial slab: part[unit][t][i][j];  tg 0 stores taps 0..4, tg 1 taps 5..8 ----------------------------------------
-  const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int sl = 0; sl < 5; ++sl) {
-    if (tg == 1 && sl == 0) continue;
-    const int t = sl + (tg == 0 ? 0 : 4);
-#pragma unroll
-    for (int ih = 0; ih < 2; ++ih) {
-      float* slab = p.part + ((long)unit * 9 + t) * p.CI * p.CJ + (long)(i0 + ih * 32 + 4 * h) * p.CJ + j0 + qj * 32 + r;
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) slab[(long)((reg & 3) + 8 * (reg >> 2)) * p.CJ] = acc[sl][ih][reg];
-    }
-  }
+  // every DMA has landed (vmcnt(0) on the last step); join of tap 4 and the slab stores
+  split_finish(acc, smem, p, unit, i0, j0, qj, tg, lane);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int PF>
+template <int PF, bool M16>
 __global__ __launch_bounds__(256, 2) void wgrad_ring_split_kernel(const WgradFusedParams p) {
   // the tap group is wave-uniform: two specialisations of the whole body, so the 160 accumulator registers of a wave
   // never meet in a phi (a per-step branch made the allocator spill ~590 registers)
-  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7) == 0) ring_split_body<PF, 0>(p);
-  else ring_split_body<PF, 1>(p);
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7) == 0) ring_split_body<PF, 0, M16>(p);
+  else ring_split_body<PF, 1, M16>(p);
 }
 
-template <int TG>
+template <int TG, bool M16>
 __device__ __forceinline__ void fused_split_body(const WgradFusedParams& p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using T = bf16_t;
@@ -634,26 +787,22 @@ __device__ __forceinline__ void fused_split_body(const WgradFusedParams& p) {
     const int gi = wave + 4 * q;
     if (gi < DYI) {
       const int row = gi * RPI + sub;                                  // pixel x0 + row
-      const int c = Frag<T, 1>::src_chunk(row, pc);
+      const int c = split_src_chunk<M16>(row, pc);
       colb[q] = (unsigned)(((x0 + row) * p.lddy + i0) * ES + c * 16);
     } else if (gi < DYI + 3 * XI) {
       const int k = (gi - DYI) % XI;
       const int row = k * RPI + sub;                                   // pixel x0 - d + row
       const int gx = x0 - p.d + row;
-      const int c = Frag<T, 1>::src_chunk(row, pc);
+      const int c = split_src_chunk<M16>(row, pc);
       colb[q] = ((unsigned)gx < (unsigned)p.W) ? (unsigned)((gx * p.ldx + j0) * ES + c * 16) : FOOB;
     } else {
       colb[q] = FOOB;
     }
   }
 
-  f32x16 acc[5][2];
-#pragma unroll
-  for (int t = 0; t < 5; ++t)
-#pragma unroll
-    for (int ih = 0; ih < 2; ++ih)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[t][ih][e] = 0.f;
+  SplitAcc<M16> acc;
+  split_zero(acc);
+  const Split16Offs offs = split_offsets<M16>(lane, qj, p.d);
 
   auto issue = [&](int stage, int y) {
 #pragma unroll
@@ -681,45 +830,19 @@ __device__ __forceinline__ void fused_split_body(const WgradFusedParams& p) {
     if (s + 1 < nsteps) issue((s + 1) & 1, ybeg + s + 1);
     const unsigned char* sdy = smem + (s & 1) * STAGE;
     const unsigned char* sx = sdy + DYB;
-    ring_split_step<TG>(acc, sdy, sx, sx + XB, sx + 2 * XB, lane, qj, p.d);
+    split_step<TG>(acc, sdy, sx, sx + XB, sx + 2 * XB, lane, qj, p.d, offs);
   }
 
-  // ---- tap 4: tg 1's half (slot 0) joins tg 0's (slot 4) through LDS (every DMA has landed: vmcnt(0) on the last step) ----
-  float* xch = reinterpret_cast<float*>(smem);
-  __syncthreads();
-  if (tg == 1) {
-#pragma unroll
-    for (int ih = 0; ih < 2; ++ih)
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) xch[((qj * 2 + ih) * 16 + reg) * 64 + lane] = acc[0][ih][reg];
-  }
-  __syncthreads();
-  if (tg == 0) {
-#pragma unroll
-    for (int ih = 0; ih < 2; ++ih)
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) acc[4][ih][reg] += xch[((qj * 2 + ih) * 16 + reg) * 64 + lane];
-  }
-  // ---- partial slab: part[unit][t][i][j];  tg 0 stores taps 0..4, tg 1 taps 5..8 ----
-  const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int sl = 0; sl < 5; ++sl) {
-    if (tg == 1 && sl == 0) continue;
-    const int t = sl + (tg == 0 ? 0 : 4);
-#pragma unroll
-    for (int ih = 0; ih < 2; ++ih) {
-      float* slab = p.part + ((long)unit * 9 + t) * p.CI * p.CJ + (long)(i0 + ih * 32 + 4 * h) * p.CJ + j0 + qj * 32 + r;
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) slab[(long)((reg & 3) + 8 * (reg >> 2)) * p.CJ] = acc[sl][ih][reg];
-    }
-  }
+  // every DMA has landed (vmcnt(0) on the last step); join of tap 4 and the slab stores
+  split_finish(acc, smem, p, unit, i0, j0, qj, tg, lane);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
 // tap-split form of the three-segment kernel (d = 4, 8): same staging, the wave roles of wgrad_ring_split_kernel
+template <bool M16>
 __global__ __launch_bounds__(256, 2) void wgrad_fused_split_kernel(const WgradFusedParams p) {
-  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7) == 0) fused_split_body<0>(p);
-  else fused_split_body<1>(p);
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7) == 0) fused_split_body<0, M16>(p);
+  else fused_split_body<1, M16>(p);
 }
 
 // LDS bytes of the ring kernel, or 0 when the configuration does not leave room for two workgroups per CU
@@ -745,22 +868,10 @@ bool wgrad_fused_supported(int N, int H, int W, int CI, int CJ, int lda, int ldb
                            int dtype) {
   if (ntaps != 9 || stride != 1 || d < 1 || d > 8) return false;
   if (CI % 64 != 0 || CJ % 64 != 0) return false;
-  static int maxc = -1, need64 = -1;
-  if (maxc < 0) {
-    const char* e = getenv("UNETDC_FUSED_MAXC");
-    maxc = e ? atoi(e) : 1024;
-    const char* f = getenv("UNETDC_FUSED_NEED64");
-    need64 = f ? atoi(f) : 0;
-  }
-  if (CI > maxc || CJ > maxc) return false;
-  if (need64 && !(CI == 64 || CJ == 64)) return false;                       // narrow layers only
+  if (CI > 1024 || CJ > 1024) return false;
   if (W % fused_seg(dtype) != 0) return false;
   const long P = (long)N * H * W;
-  static long minp = -1;
-  if (minp < 0) {
-    const char* e = getenv("UNETDC_FUSED_MINP");
-    minp = e ? atol(e) : 32L * 1024;
-  }
+  const long minp = 32L * 1024;
   if (P < minp) return false;
   const long es = dtype == UNETDC_BF16 ? 2 : 4;
   return P * lda * es < (1L << 31) && P * ldb * es < (1L << 31);
@@ -798,6 +909,8 @@ int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* 
   const int pf = ring_pf(d, dtype);
   static int split = -1;                                 // UNETDC_WGRAD_SPLIT=0: quadrant ring kernel (A/B)
   if (split < 0) { const char* e = getenv("UNETDC_WGRAD_SPLIT"); split = (e && e[0] == '0') ? 0 : 1; }
+  static int m16 = -1;                                   // UNETDC_WGRAD_M16=0: the 32x32x16 form of the tap-split kernels (A/B)
+  if (m16 < 0) { const char* e = getenv("UNETDC_WGRAD_M16"); m16 = (e && e[0] == '0') ? 0 : 1; }
   if (pf && dtype == UNETDC_BF16 && split) {
     const int lds = ring_lds(d, dtype, pf);
     long nwg = (long)units * p.itiles * p.jtiles;
@@ -808,8 +921,10 @@ int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* 
       *units_out = (W / fused_seg(dtype)) * ((N + ipu - 1) / ipu);
       nwg = (long)*units_out * p.itiles * p.jtiles;
     }
-    const void* fn = pf == 2 ? reinterpret_cast<const void*>(&wgrad_ring_split_kernel<2>)
-                             : reinterpret_cast<const void*>(&wgrad_ring_split_kernel<1>);
+    const void* fn = pf == 2 ? (m16 ? reinterpret_cast<const void*>(&wgrad_ring_split_kernel<2, true>)
+                                    : reinterpret_cast<const void*>(&wgrad_ring_split_kernel<2, false>))
+                             : (m16 ? reinterpret_cast<const void*>(&wgrad_ring_split_kernel<1, true>)
+                                    : reinterpret_cast<const void*>(&wgrad_ring_split_kernel<1, false>));
     static bool split_attr[3] = {false, false, false};
     if (!split_attr[pf]) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
@@ -819,9 +934,12 @@ int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* 
       }
       split_attr[pf] = true;
     }
-    if (pf == 2) hipLaunchKernelGGL(wgrad_ring_split_kernel<2>, dim3((unsigned)nwg), dim3(256), lds, stream, p);
-    else hipLaunchKernelGGL(wgrad_ring_split_kernel<1>, dim3((unsigned)nwg), dim3(256), lds, stream, p);
-    note_kernel(pf == 2 ? "wgrad_ring_split_kernel<2>" : "wgrad_ring_split_kernel<1>");
+    if (pf == 2 && m16) hipLaunchKernelGGL((wgrad_ring_split_kernel<2, true>), dim3((unsigned)nwg), dim3(256), lds, stream, p);
+    else if (pf == 2) hipLaunchKernelGGL((wgrad_ring_split_kernel<2, false>), dim3((unsigned)nwg), dim3(256), lds, stream, p);
+    else if (m16) hipLaunchKernelGGL((wgrad_ring_split_kernel<1, true>), dim3((unsigned)nwg), dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((wgrad_ring_split_kernel<1, false>), dim3((unsigned)nwg), dim3(256), lds, stream, p);
+    note_kernel(pf == 2 ? (m16 ? "wgrad_ring_split_kernel<2, 16x16x32>" : "wgrad_ring_split_kernel<2, 32x32x16>")
+                        : (m16 ? "wgrad_ring_split_kernel<1, 16x16x32>" : "wgrad_ring_split_kernel<1, 32x32x16>"));
     return check_launch("wgrad_ring_split_kernel");
   }
   if (pf) {
@@ -858,7 +976,8 @@ int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* 
   if (dtype == UNETDC_BF16 && split) {                   // d = 4, 8 in bf16: tap-split wave roles on the three-segment staging
     static bool sattr = false;
     if (!sattr) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fused_split_kernel),
+      hipError_t e = hipFuncSetAttribute(m16 ? reinterpret_cast<const void*>(&wgrad_fused_split_kernel<true>)
+                                             : reinterpret_cast<const void*>(&wgrad_fused_split_kernel<false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       if (e != hipSuccess) {
         set_error("hipFuncSetAttribute(wgrad_fused_split_kernel) failed: %s", hipGetErrorString(e));
@@ -866,8 +985,9 @@ int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* 
       }
       sattr = true;
     }
-    hipLaunchKernelGGL(wgrad_fused_split_kernel, dim3((unsigned)nwg), dim3(256), lds, stream, p);
-    note_kernel("wgrad_fused_split_kernel");
+    if (m16) hipLaunchKernelGGL(wgrad_fused_split_kernel<true>, dim3((unsigned)nwg), dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL(wgrad_fused_split_kernel<false>, dim3((unsigned)nwg), dim3(256), lds, stream, p);
+    note_kernel(m16 ? "wgrad_fused_split_kernel<16x16x32>" : "wgrad_fused_split_kernel<32x32x16>");
     return check_launch("wgrad_fused_split_kernel");
   }
   static bool attr_done[2] = {false, false};

@@ -44,14 +44,13 @@ FUSE_POOL_SKIP = os.environ.get("UNETDC_FUSE_POOL_SKIP", "0") == "1" and FUSE_CO
 # training step.  UNETDC_FUSE_HEAD_BN=0: stand-alone pass (A/B switch)
 FUSE_HEAD_BN = os.environ.get("UNETDC_FUSE_HEAD_BN", "1") != "0" and FUSE_BN_BWD
 # Opt-in (UNETDC_SIDE_WGRAD=1): run the weight-gradient kernels, which hang off the backward critical
-# chain, on a side HIP stream.  Measured +0.6 % on MI355X (the MFMA kernels fill the CUs' LDS, so little
-# co-residency with the HBM-bound BatchNorm passes); off by default because overlapping kernels make
-# per-kernel timings (bench.py roofline leg, rocprofv3) unattributable.
-SIDE_WGRAD = os.environ.get("UNETDC_SIDE_WGRAD", "0") in ("1", "2")
-# "2": the side stream picks a stage's weight gradient up only AFTER that stage's dgrad has been enqueued on the main stream,
-# so the MFMA-bound weight gradient runs beside the HBM-bound BatchNorm backward of the NEXT stage instead of competing
-# with its own dgrad for the matrix pipes (experiment)
-SIDE_DEFER = os.environ.get("UNETDC_SIDE_WGRAD", "0") == "2"
+# chain, on a side HIP stream.  Measured +1.3 ... +2.2 % on MI355X (round 3, same-box A/B: 11.96 / 12.03 -> 11.71 / 11.86
+# ms per step): the weight gradient of a stage fills the tail of that stage's dgrad -- NOT the HBM-bound BatchNorm passes:
+# both MFMA kernel families hold the whole register file (2 x 234-246 registers per SIMD lane), so a BatchNorm wave finds no
+# room beside them, and starting the weight gradient only behind its dgrad (so that it would run beside the next stage's
+# BatchNorm backward) gained nothing.  Off by default because overlapping kernels make per-kernel timings unattributable:
+# the roofline leg of bench.py then reads 0.38 instead of 0.49 for the dominant kernel (profiles/r03_side_stream_ab.txt).
+SIDE_WGRAD = os.environ.get("UNETDC_SIDE_WGRAD", "0") == "1"
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
@@ -428,7 +427,7 @@ class UNetEngine:
             st.dy = torch.empty(st.npix, st.cout, device=dev, dtype=dt)
         self.grad_bufs = g
         self.workspace = torch.empty(self.ws_bytes, device=dev, dtype=torch.uint8)
-        self.side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("UNETDC_SIDE_PRIO", "0"))) if SIDE_WGRAD else None
+        self.side = torch.cuda.Stream(device=dev) if SIDE_WGRAD else None
         self.ws_side = torch.empty(self.ws_bytes, device=dev, dtype=torch.uint8) if SIDE_WGRAD else self.workspace
 
     def _side_after_main(self):
@@ -512,11 +511,8 @@ class UNetEngine:
                     call("unetdc_conv3x3_wgrad", xin.data_ptr(), xin.stride(0), dy.data_ptr(), dy.stride(0), dw.data_ptr(),
                          ws2, wsb, N, h, w, st.cin, st.cout, st.dil, self.dt, s2)
 
-        if not SIDE_DEFER:
-            wgrad()
+        wgrad()
         self._stage_dgrad(st, dx_out, fuse_prev, colsum, skip_for, dy, ws, wsb, N, h, w, s)
-        if SIDE_DEFER:
-            wgrad()
 
     def _stage_dgrad(self, st, dx_out, fuse_prev, colsum, skip_for, dy, ws, wsb, N, h, w, s):
         if not st.first:
