@@ -322,11 +322,11 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 // NORM: `a` is the raw conv output of the producing stage and the BatchNorm + ReLU of that stage is applied on load,
 // a = relu(scale * y + shift) rounded through the storage type (exactly the values a stand-alone normalisation pass
 // would have stored): the activation tensor is never written or read.
-template <typename T, bool NORM>
+template <typename T, bool NORM, int CPP>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadParams p) {
   constexpr int EPC = Chunk<T>::N;
   constexpr int UNR = 4;                              // pixels per lane group and trip: four 16-byte loads in flight
-  const int cpp = p.C / EPC;                          // lanes per pixel (power of two, <= 64)
+  const int cpp = CPP ? CPP : p.C / EPC;              // lanes per pixel (power of two, <= 64); CPP > 0: known at compile time
   const int ppb = 256 / cpp;
   const int tid = threadIdx.x, cl = tid % cpp, pl = tid / cpp;
   const long HW = (long)p.H * p.W, P = (long)p.N * HW;
@@ -355,20 +355,47 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadParams p) {
 #pragma unroll
       for (int e = 0; e < EPC; ++e) wv[e] = p.w[oc * p.C + cl * EPC + e];
       const float bias = p.b[oc];
+      // the four dot products of a trip are reduced TOGETHER, step by step: four independent shuffle chains instead of four
+      // serial ones (a cross-lane step is an LDS-crossbar round trip; with a runtime lane count the loop was not unrolled
+      // and the kernel ran at 2.9 TB/s on shuffle latency)
+      float sv[UNR];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
-        const bool ok = pix[u] < P;
-        float s = 0.f;
-        if (ok) {
+        sv[u] = 0.f;
+        if (pix[u] < P) {
 #pragma unroll
-          for (int e = 0; e < EPC; ++e) s = fmaf(v[u][e], wv[e], s);
+          for (int e = 0; e < EPC; ++e) sv[u] = fmaf(v[u][e], wv[e], sv[u]);
         }
-        for (int o = 1; o < cpp; o <<= 1) s += __shfl_xor(s, o, 64);
-        if (ok && cl == 0) {
-          const float z = s + bias;
-          const long n = pix[u] / HW, rem = pix[u] - n * HW;
-          p.probs[(n * p.OC + oc) * HW + rem] = 1.f / (1.f + expf(-z));
+      }
+      if (CPP) {
+#pragma unroll
+        for (int o = 1; o < (CPP ? CPP : 1); o <<= 1)
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) sv[u] += __shfl_xor(sv[u], o, 64);
+      } else {
+        for (int o = 1; o < cpp; o <<= 1)
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) sv[u] += __shfl_xor(sv[u], o, 64);
+      }
+      // every lane of the group holds the four sums: lane u finishes pixel u (sigmoid + store)
+      if (cpp >= UNR) {
+        float z = sv[0];
+#pragma unroll
+        for (int u = 1; u < UNR; ++u) z = (cl == u) ? sv[u] : z;
+        if (cl < UNR) {
+          const long px = pb + cl * ppb + pl;
+          if (px < P) {
+            const long n = px / HW, rem = px - n * HW;
+            p.probs[(n * p.OC + oc) * HW + rem] = 1.f / (1.f + expf(-(z + bias)));
+          }
         }
+      } else {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+          if (pix[u] < P && cl == 0) {
+            const long n = pix[u] / HW, rem = pix[u] - n * HW;
+            p.probs[(n * p.OC + oc) * HW + rem] = 1.f / (1.f + expf(-(sv[u] + bias)));
+          }
       }
     }
   }
@@ -404,36 +431,55 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadParams p) {
     float wv[EPC], gw[EPC], gb = 0.f;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { wv[e] = p.w[oc * p.C + cl * EPC + e]; gw[e] = 0.f; }
-    for (long pb = (long)blockIdx.x * ppb; pb < P; pb += (long)gridDim.x * ppb) {
-      const long pix = pb + pl;
-      if (pix >= P) continue;
-      const long n = pix / HW, rem = pix - n * HW;
-      const long o = (n * p.OC + oc) * HW + rem;
-      const float pr = p.probs[o];
-      const float dz = p.dprobs[o] * pr * (1.f - pr);
-      float av[EPC], d[EPC], yv[EPC];
-      if (BN && (last || !ag)) Chunk<T>::unpack(ld16(yg + pix * p.bn_ldy + cl * EPC), yv);
-      if (!BN || ag) Chunk<T>::unpack(ld16(ag + pix * p.lda + cl * EPC), av);
-      else {                                             // the activation as the forward pass saw it, from the saved conv output
+    // two pixels per lane group and trip: every load of both is issued before the arithmetic of the first (one 16-byte load
+    // in flight per lane at 3 waves per SIMD left the kernel latency bound at 3.4 TB/s)
+    constexpr int U = 2;
+    for (long pb = (long)blockIdx.x * ppb * U; pb < P; pb += (long)gridDim.x * ppb * U) {
+      long pix[U];
+      bool ok[U];
+      u32x4 yraw[U], araw[U], draw[U];
+      float pr[U], dpv[U];
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) av[e] = round_through<T>(fmaxf(fmaf(yv[e], sc[e], sh[e]), 0.f));
+      for (int u = 0; u < U; ++u) {
+        pix[u] = pb + u * ppb + pl;
+        ok[u] = pix[u] < P;
+        const long px = ok[u] ? pix[u] : 0;
+        const long n = px / HW, rem = px - n * HW;
+        const long o = (n * p.OC + oc) * HW + rem;
+        pr[u] = p.probs[o];
+        dpv[u] = p.dprobs[o];
+        if (BN && (last || !ag)) yraw[u] = ld16(yg + px * p.bn_ldy + cl * EPC);
+        if (!BN || ag) araw[u] = ld16(ag + px * p.lda + cl * EPC);
+        if (oc > 0) draw[u] = ld16(dag + px * p.ldda + cl * EPC);
       }
-      if (oc > 0) Chunk<T>::unpack(ld16(dag + pix * p.ldda + cl * EPC), d);
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) {
-        gw[e] = fmaf(dz, av[e], gw[e]);
-        d[e] = (oc > 0 ? d[e] : 0.f) + dz * wv[e];
-      }
-      if (cl == 0) gb += dz;
-      st16(dag + pix * p.ldda + cl * EPC, Chunk<T>::pack(d));
-      if (BN && last) {
+      for (int u = 0; u < U; ++u) {
+        if (!ok[u]) continue;
+        const float dz = dpv[u] * pr[u] * (1.f - pr[u]);
+        float av[EPC], d[EPC], yv[EPC];
+        if (BN && (last || !ag)) Chunk<T>::unpack(yraw[u], yv);
+        if (!BN || ag) Chunk<T>::unpack(araw[u], av);
+        else {                                           // the activation as the forward pass saw it, from the saved conv output
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) av[e] = round_through<T>(fmaxf(fmaf(yv[e], sc[e], sh[e]), 0.f));
+        }
+        if (oc > 0) Chunk<T>::unpack(draw[u], d);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-          const float g = round_through<T>(d[e]);
-          const float nrm = fmaf(yv[e], sc[e], sh[e]);
-          const float gh = nrm > 0.f ? g : 0.f;
-          const float xh = (yv[e] - mu[e]) * rs[e];
-          s1[e] += gh; s2[e] = fmaf(gh, xh, s2[e]); s3[e] += xh;
+          gw[e] = fmaf(dz, av[e], gw[e]);
+          d[e] = (oc > 0 ? d[e] : 0.f) + dz * wv[e];
+        }
+        if (cl == 0) gb += dz;
+        st16(dag + pix[u] * p.ldda + cl * EPC, Chunk<T>::pack(d));
+        if (BN && last) {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            const float g = round_through<T>(d[e]);
+            const float nrm = fmaf(yv[e], sc[e], sh[e]);
+            const float gh = nrm > 0.f ? g : 0.f;
+            const float xh = (yv[e] - mu[e]) * rs[e];
+            s1[e] += gh; s2[e] = fmaf(gh, xh, s2[e]); s3[e] += xh;
+          }
         }
       }
     }
@@ -864,12 +910,18 @@ int launch_head_fwd(HeadParams& p, int dtype, hipStream_t stream) {
   const int nb = grid_for((long)p.N * p.H * p.W, 4 * (256 / (p.C / epc)));     // UNR = 4 pixels per lane group and trip
   const bool norm = p.bn_scale != nullptr;             // BatchNorm + ReLU of the producing stage applied on load
   if (norm) UNETDC_REQUIRE(p.bn_shift != nullptr, "head_fwd_bn: null shift");
+  // C = 64 (the networks' head): 8 (bf16) / 16 (fp32) lanes per pixel known at compile time; other widths: generic form
+  const bool c64 = p.C == 64;
   if (dtype == UNETDC_BF16) {
-    if (norm) hipLaunchKernelGGL((head_fwd_kernel<bf16_t, true>), dim3(nb), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((head_fwd_kernel<bf16_t, false>), dim3(nb), dim3(256), 0, stream, p);
+    if (norm && c64) hipLaunchKernelGGL((head_fwd_kernel<bf16_t, true, 8>), dim3(nb), dim3(256), 0, stream, p);
+    else if (norm) hipLaunchKernelGGL((head_fwd_kernel<bf16_t, true, 0>), dim3(nb), dim3(256), 0, stream, p);
+    else if (c64) hipLaunchKernelGGL((head_fwd_kernel<bf16_t, false, 8>), dim3(nb), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((head_fwd_kernel<bf16_t, false, 0>), dim3(nb), dim3(256), 0, stream, p);
   } else {
-    if (norm) hipLaunchKernelGGL((head_fwd_kernel<float, true>), dim3(nb), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((head_fwd_kernel<float, false>), dim3(nb), dim3(256), 0, stream, p);
+    if (norm && c64) hipLaunchKernelGGL((head_fwd_kernel<float, true, 16>), dim3(nb), dim3(256), 0, stream, p);
+    else if (norm) hipLaunchKernelGGL((head_fwd_kernel<float, true, 0>), dim3(nb), dim3(256), 0, stream, p);
+    else if (c64) hipLaunchKernelGGL((head_fwd_kernel<float, false, 16>), dim3(nb), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((head_fwd_kernel<float, false, 0>), dim3(nb), dim3(256), 0, stream, p);
   }
   return check_launch("head_fwd_kernel");
 }
