@@ -34,19 +34,14 @@ namespace unetdc {
 constexpr unsigned OOB16 = 0x80000000u;
 
 // WM x WN waves; each wave owns (TMT*16) x 64 outputs (TMT x 4 MFMA 16x16 tiles).
-// BREG: the weight (B) operand does not go through LDS at all.  The packed weights are K-contiguous, so a lane's B fragment of
-// v_mfma_f32_16x16x32_bf16 (one channel row, 8 consecutive K) is ONE 16-byte global load; a wave fetches the eight fragments
-// of its 64-channel slice for the next K step into a second register set while it computes the current one.  Only the pixel
-// (A) tile is staged by LDS-DMA: half the bytes on the L2 -> LDS path that bounds this kernel (a 1-tap GEMM has no patch to
-// reuse), half the LDS fragment reads.  The WM waves that share a channel slice fetch it WM times (vector L1 hits).
-template <int WM, int WN, int TMT, bool BREG>
+template <int WM, int WN, int TMT>
 __global__ __launch_bounds__(512, 2) void igemm_dma16_kernel(const IgemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NW = WM * WN;
   constexpr int BM = WM * TMT * 16, BN = WN * 64;
   constexpr int AI = BM / 8 / NW, BI = BN / 8 / NW;
   constexpr int ES = 2, KE = 64;
-  constexpr int STAGE = (BM + (BREG ? 0 : BN)) * 128;
+  constexpr int STAGE = (BM + BN) * 128;
   static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/wave mismatch");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -135,13 +130,6 @@ __global__ __launch_bounds__(512, 2) void igemm_dma16_kernel(const IgemmParams p
   }
   const int nkc = p.Cin / KE;
   const int nsteps = __popc(tapmask) * nkc;
-  // BREG: per-lane byte offset of this lane's row of N tile j (channel n0 + wn*64 + 4*c + j, chunk rb of the 64-element K step)
-  unsigned bfrag[4];
-  if (BREG) {
-    const int c16b = lane & 15, rbb = lane >> 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bfrag[j] = (unsigned)((n0 + wn * 64 + 4 * c16b + j) * p.Cin * ES + rbb * 16);
-  }
 
   // fragment read offsets: row c of a tile, chunk 4*g + rb (swizzle is the same for every 16-row tile)
   const int c16 = lane & 15, rb = lane >> 4;
@@ -163,7 +151,6 @@ __global__ __launch_bounds__(512, 2) void igemm_dma16_kernel(const IgemmParams p
       for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
   int lt = 0, lkc = 0;
-  unsigned wnext = 0;                               // scalar weight offset (tap, K chunk) of the step issue() has just staged
   while (lt < p.ntaps && !((tapmask >> lt) & 1u)) ++lt;
 
   auto issue = [&](int stage) {
@@ -178,13 +165,10 @@ __global__ __launch_bounds__(512, 2) void igemm_dma16_kernel(const IgemmParams p
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, LDS_PTR16(sbase + (wave + NW * j) * 1024), 16, voff, 0, 0, 0);
     }
     const unsigned wbytes_t = (unsigned)(lt * p.Cout * p.Cin * ES + lkc * 128);
-    if (!BREG) {
 #pragma unroll
-      for (int j = 0; j < BI; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, LDS_PTR16(sbase + BM * 128 + (wave + NW * j) * 1024), 16,
-                                                 bbase[j] + wbytes_t, 0, 0, 0);
-    }
-    wnext = wbytes_t;
+    for (int j = 0; j < BI; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, LDS_PTR16(sbase + BM * 128 + (wave + NW * j) * 1024), 16,
+                                               bbase[j] + wbytes_t, 0, 0, 0);
     // K order: 64-channel chunk OUTER, tap INNER.  The nine taps of one chunk re-read (shifted) the same 32 KB of
     // input, back to back, so they hit in the XCD's 4 MB L2; with the tap outer a workgroup streamed its whole
     // 256-pixel x Cin slab between two uses and every tap came from beyond L2 (PMC: 2.1x the algorithmic bytes).
@@ -196,56 +180,26 @@ __global__ __launch_bounds__(512, 2) void igemm_dma16_kernel(const IgemmParams p
     }
   };
 
-  // one K step on stage `st`: with BREG the B fragments come from the register set `fbr`
-  auto compute = [&](int st, const u32x4 (&fbr)[2][4]) {
-    const unsigned char* base = smem + st * STAGE;
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      constexpr int AH = BREG ? (TMT < 4 ? TMT : 4) : TMT;      // BREG: A fragments in groups of four (registers)
-      u32x4 fb[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = BREG ? fbr[g][j] : ld16(base + b_rd[g] + j * 16 * 128);
-#pragma unroll
-      for (int i0 = 0; i0 < TMT; i0 += AH) {
-        u32x4 fa[AH];
-#pragma unroll
-        for (int i = 0; i < AH; ++i) fa[i] = ld16(base + a_rd[g] + (i0 + i) * 16 * 128);
-#pragma unroll
-        for (int i = 0; i < AH; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]),
-                                                                     __builtin_bit_cast(bf16x8, fb[j]), acc[i0 + i][j], 0, 0, 0);
-      }
-    }
-  };
-  auto load_b = [&](u32x4 (&fbr)[2][4]) {           // fragments of the step issue() has just staged (wnext)
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fbr[g][j] = __builtin_amdgcn_raw_buffer_load_b128(wr, bfrag[j] + (unsigned)(g * 64), wnext, 0);
-  };
-  // ONE compute site (two, with a register set each, made the compiler keep two copies of the accumulators): the set
-  // fetched during step s - 1 is moved into the working set behind the barrier (32 v_mov against 64 x TMT / 4 MFMAs)
-  u32x4 fbw[2][4], fbn[2][4];
-  if (nsteps > 0) {
-    issue(0);
-    if (BREG) load_b(fbn);
-  }
+  if (nsteps > 0) issue(0);
   for (int s = 0; s < nsteps; ++s) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (BREG) {
+    if (s + 1 < nsteps) issue((s + 1) & 1);
+    const unsigned char* base = smem + (s & 1) * STAGE;
 #pragma unroll
-      for (int g = 0; g < 2; ++g)
+    for (int g = 0; g < 2; ++g) {
+      u32x4 fa[TMT], fb[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fbw[g][j] = fbn[g][j];
+      for (int j = 0; j < 4; ++j) fb[j] = ld16(base + b_rd[g] + j * 16 * 128);
+#pragma unroll
+      for (int i = 0; i < TMT; ++i) fa[i] = ld16(base + a_rd[g] + i * 16 * 128);
+#pragma unroll
+      for (int i = 0; i < TMT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
+                                                              acc[i][j], 0, 0, 0);
     }
-    if (s + 1 < nsteps) {
-      issue((s + 1) & 1);
-      if (BREG) load_b(fbn);
-    }
-    compute(s & 1, fbw);
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------------
@@ -296,13 +250,13 @@ __global__ __launch_bounds__(512, 2) void igemm_dma16_kernel(const IgemmParams p
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int WM, int WN, int TMT, bool BREG>
+template <int WM, int WN, int TMT>
 static int launch_dma16_cfg(IgemmParams& p, hipStream_t stream) {
   constexpr int BM = WM * TMT * 16, BN = WN * 64;
-  constexpr int LDS = 2 * (BM + (BREG ? 0 : BN)) * 128 + (BREG ? WM * WN * 512 : 0);   // BREG: + room for the statistics scratch
+  constexpr int LDS = 2 * (BM + BN) * 128;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma16_kernel<WM, WN, TMT, BREG>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma16_kernel<WM, WN, TMT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       set_error("hipFuncSetAttribute(igemm_dma16_kernel) failed: %s", hipGetErrorString(e));
@@ -323,9 +277,9 @@ static int launch_dma16_cfg(IgemmParams& p, hipStream_t stream) {
     p.quad_bpi = (p.Ho / 16) * p.quad_bpr;
   }
   const long nwg = (long)p.mblocks * p.nblocks;
-  hipLaunchKernelGGL((igemm_dma16_kernel<WM, WN, TMT, BREG>), dim3((unsigned)nwg), dim3(WM * WN * 64), LDS, stream, p);
+  hipLaunchKernelGGL((igemm_dma16_kernel<WM, WN, TMT>), dim3((unsigned)nwg), dim3(WM * WN * 64), LDS, stream, p);
   char nm[96];
-  snprintf(nm, sizeof(nm), "igemm_dma16_kernel<%d, %d, %d%s>%s", WM, WN, TMT, BREG ? ", Breg" : "", p.quad_bpr ? " blocks16x16" : "");
+  snprintf(nm, sizeof(nm), "igemm_dma16_kernel<%d, %d, %d>%s", WM, WN, TMT, p.quad_bpr ? " blocks16x16" : "");
   note_kernel(nm);
   return check_launch("igemm_dma16_kernel");
 }
@@ -339,11 +293,9 @@ bool igemm_dma16_supported(const IgemmParams& p, int dtype) {
 
 // cfg: 1 = 256x256 (8 waves), 2 = 256x128 (8 waves), 3 = 256x64 (4 waves) -- chosen by launch_igemm_dma
 int launch_igemm_dma16(IgemmParams& p, int cfg, hipStream_t stream) {
-  static int breg = -1;                                  // UNETDC_DMA16_BREG=0: weights through LDS like the pixels (A/B)
-  if (breg < 0) { const char* e = getenv("UNETDC_DMA16_BREG"); breg = (e && e[0] == '0') ? 0 : 1; }
-  if (cfg == 1) return breg ? launch_dma16_cfg<2, 4, 8, true>(p, stream) : launch_dma16_cfg<2, 4, 8, false>(p, stream);
-  if (cfg == 2) return breg ? launch_dma16_cfg<4, 2, 4, true>(p, stream) : launch_dma16_cfg<4, 2, 4, false>(p, stream);
-  return breg ? launch_dma16_cfg<4, 1, 4, true>(p, stream) : launch_dma16_cfg<4, 1, 4, false>(p, stream);
+  if (cfg == 1) return launch_dma16_cfg<2, 4, 8>(p, stream);
+  if (cfg == 2) return launch_dma16_cfg<4, 2, 4>(p, stream);
+  return launch_dma16_cfg<4, 1, 4>(p, stream);
 }
 
 }  // namespace unetdc
