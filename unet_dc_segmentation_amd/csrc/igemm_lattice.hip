@@ -65,14 +65,7 @@ template <int PJ, int SPT> __device__ constexpr int lat_nsl(int t) {
 }
 #endif
 
-// RESW (64 -> 64 channels, the level-1 layers): ALL NINE weight taps (9 x 8 KB) stay resident in LDS for the whole launch and
-// the patch is double-buffered, one workgroup per CU (2 x 44 KB + 72 KB = the whole 160 KB; the statistics scratch sits in
-// the two 1 KB pads behind the patches, whose padding slice is not issued).  These layers move 64 KB of activations per
-// 256-pixel item against 2.2 us of MFMA work: they are HBM bound, and the single-buffer form (two workgroups per CU, the
-// next patch requested only behind the last tap) left the memory pipe idle while both workgroups computed -- 10.6 us per
-// item and workgroup, of which 7 were spent waiting for the patch.  Here the next item's patch is in flight during the whole
-// current item, there is no weight traffic and no per-tap barrier or wait: one wait + one barrier per item.
-template <int WM, int WN, int MT, int NPB, int MODE, bool RESW = false>
+template <int WM, int WN, int MT, int NPB, int MODE>
 __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const IgemmParams p, const LatticeParams q) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NW = WM * WN, BN = WN * 64;
@@ -81,12 +74,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
   constexpr int SPT = (NW == 4) ? 3 : 2;          // patch slices per tap while prefetching
   constexpr int PBUF = PJ * NW * 1024;            // bytes per patch buffer
   constexpr int WST = BN * 128;                   // bytes per weight stage
-  constexpr int NSTG = RESW ? 9 : 3;              // weight stages: a ring of three, or every tap resident
-  constexpr int OFF_W = NPB * PBUF, OFF_RED = OFF_W + NSTG * WST;
+  constexpr int OFF_W = NPB * PBUF, OFF_RED = OFF_W + 3 * WST;
   constexpr int NST = MT * 4;                     // epilogue stores per wave and tile
   static_assert(WM * MT == 16 && (MT % 2) == 0, "a workgroup owns 16 M-tiles = 8 rows x 32 pixels");
   static_assert(BN % (8 * NW) == 0, "weight rows / wave mismatch");
-  static_assert(!RESW || (NW == 4 && NPB == 2 && BN == 64), "resident weights: the 4-wave 64-channel form with two patch buffers");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -188,21 +179,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
                  : 32u;
   };
   auto issue_slice = [&](int sl, int buf, unsigned pbase, unsigned edges) {
-    if (RESW && wave + NW * sl >= LPI) return;    // the padding slice behind the patch: its 1 KB holds the statistics scratch
     const int pr = (wave + NW * sl) * 8 + sub;
     const int ppy = (pr * 1928) >> 16, ppx = pr - ppy * LPW;       // pr / 34 for pr < 1024
     const int ch = pc ^ ((ppx >> 1) & 7);
     const unsigned rel = (unsigned)(((ppy * d) * p.Wi + ppx * d) * p.ldx * 2 + ch * 16);
     const unsigned f = ((ppy == 0 ? 1u : 0u) | (ppy == LPH - 1 ? 2u : 0u) | (ppx == 0 ? 4u : 0u) | (ppx == LPW - 1 ? 8u : 0u) |
                         (pr >= LPP ? 16u : 0u) | 32u) & edges;
-    // (RESW: the buffer index is a loop-carried toggle that the compiler may keep in a VGPR; M0 needs an SGPR)
-    const unsigned dst = RESW ? (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + buf * PBUF + (wave + NW * sl) * 1024))
-                              : lds_base + buf * PBUF + (wave + NW * sl) * 1024;
-    lds_dma16(xr, dst, f ? LOOB : rel, pbase);
-  };
-  // statistics scratch of wave w2: [4 k][2][16 c] floats = 512 bytes
-  auto red_of = [&](int w2) -> float* {
-    return reinterpret_cast<float*>(RESW ? smem + (w2 >> 1) * PBUF + LPI * 1024 + (w2 & 1) * 512 : smem + OFF_RED + w2 * 512);
+    lds_dma16(xr, lds_base + buf * PBUF + (wave + NW * sl) * 1024, f ? LOOB : rel, pbase);
   };
   auto issue_w = [&](int stage, int tap, int kc, int nblk, bool valid) {
     const unsigned soff = (unsigned)(((tap * p.Cout + nblk * BN) * p.Cin + kc * 64) * 2);
@@ -312,12 +295,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
         s4[k] += __shfl_xor(s4[k], 16, 64); q4[k] += __shfl_xor(q4[k], 16, 64);
         s4[k] += __shfl_xor(s4[k], 32, 64); q4[k] += __shfl_xor(q4[k], 32, 64);
       }
-      float* red = red_of(wave);                                             // [4 k][2][16 c] per wave
+      float* red = reinterpret_cast<float*>(smem + OFF_RED);                 // [wave][4 k][2][16 c]
       if (rb == 0) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          red[(k * 2 + 0) * 16 + c16] = s4[k];
-          red[(k * 2 + 1) * 16 + c16] = q4[k];
+          red[((wave * 4 + k) * 2 + 0) * 16 + c16] = s4[k];
+          red[((wave * 4 + k) * 2 + 1) * 16 + c16] = q4[k];
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -327,9 +310,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
         float su = 0.f, sq = 0.f;
 #pragma unroll
         for (int w2 = 0; w2 < WM; ++w2) {
-          const float* r2 = red_of(w2 * WN + wn2);
-          su += r2[(k * 2 + 0) * 16 + c2];
-          sq += r2[(k * 2 + 1) * 16 + c2];
+          su += red[(((w2 * WN + wn2) * 4 + k) * 2 + 0) * 16 + c2];
+          sq += red[(((w2 * WN + wn2) * 4 + k) * 2 + 1) * 16 + c2];
         }
         tot_su += su;                                       // tiles in the order this workgroup visits them: reproducible
         tot_sq += sq;
@@ -345,51 +327,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
   int item = first;
   load_consts(cur.nblk);
   zero_acc();
-  if (RESW) {
-    // ---- resident weights: one wait + one barrier per item ----------------------------------------------------------------
-    // VM queue at the top of an item: [this item's patch slices (issued during the previous item's taps)] [the previous
-    // item's prefetched y, consumed by its epilogue] [its NST epilogue stores]: everything but the stores must have landed.
-#pragma unroll
-    for (int t = 0; t < 9; ++t) issue_w(t, t, 0, cur.nblk, true);
-#pragma unroll
-    for (int sl = 0; sl < PJ; ++sl) issue_slice(sl, 0, patch_base(cur, 0), patch_edges(cur, true));
-    int cbuf = 0;
-    bool boundary = false;
-    for (;;) {
-      const int item_n = item + G;
-      const bool have_n = item_n < q.items;
-      nxt = have_n ? decode(item_n) : cur;
-      const unsigned pb_n = (unsigned)__builtin_amdgcn_readfirstlane((int)patch_base(nxt, 0));
-      const unsigned pe_n = (unsigned)__builtin_amdgcn_readfirstlane((int)patch_edges(nxt, true));
-      int ab[3][2];
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-        for (int g = 0; g < 2; ++g) ab[kx][g] = aoff[kx][g] + cbuf * PBUF;
-      if (boundary) wait_vmcnt<NST>(); else wait_vmcnt<0>();
-      raw_barrier();                              // every wave's pieces of this patch have landed; the other buffer is free
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        if (have_n) {
-#pragma unroll
-          for (int u = 0; u < SPT; ++u)
-            if (t * SPT + u < PJ) issue_slice(t * SPT + u, cbuf ^ 1, pb_n, pe_n);
-        }
-        if (MODE == MODE_BNBWD && t == YT) {
-          unsigned voff[MT], yoff[MT];
-          item_offsets(cur, voff, yoff);
-          epi16_prefetch_y<MT>(p, yoff, 2u * (unsigned)d * ldyb, ypre);
-        }
-        compute_tap(t / 3, t % 3, t, ab);
-      }
-      epilogue(cur);
-      boundary = true;
-      cbuf ^= 1;
-      item = item_n;
-      if (!have_n) break;
-      cur = nxt;
-    }
-  } else {
   {
     if (NPB == 1) { issue_w(0, 0, 0, cur.nblk, true); issue_w(1, 1, 0, cur.nblk, true); }
 #pragma unroll
@@ -468,7 +405,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
     if (item >= q.items) break;
     if (nxt.nblk != cur.nblk) { load_consts(nxt.nblk); zero_acc(); }
     cur = nxt;
-  }
   }
   if ((MODE == MODE_STATS || MODE == MODE_BNBWD) && tid < BN) {
     constexpr int nrow = (MODE == MODE_BNBWD) ? 3 : 2;
@@ -845,16 +781,14 @@ static long lattice_grid(long items, int wgs_per_cu) {
   return g > items ? items : g;
 }
 
-template <int WM, int WN, int MT, int NPB, int MODE, bool RESW = false>
+template <int WM, int WN, int MT, int NPB, int MODE>
 static int launch_lattice_cfg(IgemmParams& p, const LatticeParams& q, int wgs_per_cu, hipStream_t stream) {
   constexpr int NW = WM * WN, BN = WN * 64;
   constexpr int PJ = (LPI + NW - 1) / NW;
-  constexpr int LDS = RESW ? NPB * PJ * NW * 1024 + 9 * BN * 128                       // = 163840: the whole 160 KB
-                           : NPB * PJ * NW * 1024 + 3 * BN * 128 + NW * 128 * 4;
-  static_assert(LDS <= 163840, "LDS budget");
+  constexpr int LDS = NPB * PJ * NW * 1024 + 3 * BN * 128 + NW * 128 * 4;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_lattice_kernel<WM, WN, MT, NPB, MODE, RESW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_lattice_kernel<WM, WN, MT, NPB, MODE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       set_error("hipFuncSetAttribute(igemm_lattice_kernel) failed: %s", hipGetErrorString(e));
@@ -868,9 +802,9 @@ static int launch_lattice_cfg(IgemmParams& p, const LatticeParams& q, int wgs_pe
     set_error("igemm_lattice: grid %ld / nblocks %d / stat_rows %d inconsistent", grid, q.nblocks, q.stat_rows);
     return UNETDC_ELAUNCH;
   }
-  hipLaunchKernelGGL((igemm_lattice_kernel<WM, WN, MT, NPB, MODE, RESW>), dim3((unsigned)grid), dim3(NW * 64), LDS, stream, p, q);
+  hipLaunchKernelGGL((igemm_lattice_kernel<WM, WN, MT, NPB, MODE>), dim3((unsigned)grid), dim3(NW * 64), LDS, stream, p, q);
   char nm[96];
-  snprintf(nm, sizeof(nm), "igemm_lattice_kernel<%d, %d, %d, %d, %d%s>", WM, WN, MT, NPB, MODE, RESW ? ", resident weights" : "");
+  snprintf(nm, sizeof(nm), "igemm_lattice_kernel<%d, %d, %d, %d, %d>", WM, WN, MT, NPB, MODE);
   note_kernel(nm);
   return check_launch("igemm_lattice_kernel");
 }
@@ -901,13 +835,13 @@ static int launch_lattice_wide_cfg(IgemmParams& p, const LatticeParams& q, hipSt
   return check_launch("igemm_lattice_wide_kernel");
 }
 
-template <int WM, int WN, int MT, int NPB, bool RESW = false>
+template <int WM, int WN, int MT, int NPB>
 static int launch_lattice_mode(IgemmParams& p, const LatticeParams& q, int wgs, hipStream_t stream) {
   switch (p.mode) {
-    case MODE_STATS: return launch_lattice_cfg<WM, WN, MT, NPB, MODE_STATS, RESW>(p, q, wgs, stream);
-    case MODE_AFFINE_RELU: return launch_lattice_cfg<WM, WN, MT, NPB, MODE_AFFINE_RELU, RESW>(p, q, wgs, stream);
-    case MODE_BNBWD: return launch_lattice_cfg<WM, WN, MT, NPB, MODE_BNBWD, RESW>(p, q, wgs, stream);
-    default: return launch_lattice_cfg<WM, WN, MT, NPB, MODE_STORE, RESW>(p, q, wgs, stream);
+    case MODE_STATS: return launch_lattice_cfg<WM, WN, MT, NPB, MODE_STATS>(p, q, wgs, stream);
+    case MODE_AFFINE_RELU: return launch_lattice_cfg<WM, WN, MT, NPB, MODE_AFFINE_RELU>(p, q, wgs, stream);
+    case MODE_BNBWD: return launch_lattice_cfg<WM, WN, MT, NPB, MODE_BNBWD>(p, q, wgs, stream);
+    default: return launch_lattice_cfg<WM, WN, MT, NPB, MODE_STORE>(p, q, wgs, stream);
   }
 }
 
@@ -933,11 +867,7 @@ int launch_igemm_lattice(IgemmParams& p, hipStream_t stream) {
   // forms; the plain-store instantiation spills 36 registers -- its reloads would drain the VM counter in front of the
   // hand-placed DMAs -- and keeps the 8-wave form (4 x 2 waves of 64 x 64, two patch buffers)
   const bool ww = wide && (p.mode == MODE_STATS || p.mode == MODE_AFFINE_RELU || p.mode == MODE_BNBWD);
-  // 64 -> 64 channels (level 1): every weight tap resident in LDS, double-buffered patch, one workgroup per CU
-  static int resw_on = -1;                        // UNETDC_LAT_RESW=0: the single-buffer two-workgroups-per-CU form (A/B)
-  if (resw_on < 0) { const char* e = getenv("UNETDC_LAT_RESW"); resw_on = (e && e[0] == '0') ? 0 : 1; }
-  const bool resw = resw_on && !wide && p.Cin == 64 && p.Cout == 64;
-  const int wgs = ((wide && !ww) || resw) ? 1 : 2;   // workgroups per CU of the configurations
+  const int wgs = (wide && !ww) ? 1 : 2;          // workgroups per CU of the configurations
   q.nblocks = p.Cout / (wide ? 128 : 64);
   q.items = q.mtiles * q.nblocks;
   // statistics: one row per workgroup and n-block (the kernel zero-fills the rest of the M / 256 rows).  The grid is
@@ -953,7 +883,6 @@ int launch_igemm_lattice(IgemmParams& p, hipStream_t stream) {
     return launch_lattice_wide_cfg<MODE_AFFINE_RELU>(p, q, stream);
   }
   if (wide) return launch_lattice_mode<4, 2, 4, 2>(p, q, 1, stream);
-  if (resw) return launch_lattice_mode<4, 1, 4, 2, true>(p, q, 1, stream);
   return launch_lattice_mode<4, 1, 4, 1>(p, q, 2, stream);
 }
 
