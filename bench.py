@@ -90,7 +90,7 @@ def pmc_traffic(kernel):
     """Per-launch bytes past the L2 for `kernel` from the committed rocprofv3 PMC summary (separate FETCH_SIZE /
     WRITE_SIZE passes, gfx950 x2 correction on the read side; tools/pmc_traffic.sh), or None -- also None when the
     summary was measured on different kernel sources than the ones built here (source-hash stamp)."""
-    for tag in ("r02", "r01"):
+    for tag in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
         try:
             doc = json.load(open(path))

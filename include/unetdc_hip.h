@@ -123,6 +123,11 @@ int64_t unetdc_conv3x3_first_wgrad_workspace(int n, int h, int w, int cin, int c
 int unetdc_conv3x3_first_wgrad(const float* x_nchw, const void* dy, int lddy, float* dw, void* workspace,
                                int64_t workspace_bytes, int n, int h, int w, int cin, int cout, int dilation,
                                int dtype, unetdc_stream_t s);
+/* Gradient with respect to the INPUT image, dL/dx of the module's forward (autograd of the first nn.Conv2d, models/model_2.py:
+ * 10,41-44,58; the reference's loops never request it, a saliency-style caller does): dx NCHW fp32 [n][cin][h][w] from the
+ * gradient dy [n*h*w][lddy] of the first convolution's output and its fp32 weights in PyTorch layout [cout][cin][3][3]. */
+int unetdc_conv3x3_first_dgrad(const void* dy, int lddy, const float* w, float* dx_nchw, int n, int h, int wd, int cin,
+                               int cout, int dilation, int dtype, unetdc_stream_t s);
 
 /* ---- ConvTranspose2d(k=2, s=2): models/model_2.py:20,23,26,29 and :67,70,73,76 -----------------
  * fwd: x [n,h,w,cin] -> up [n,2h,2w,cout] (+bias) written with pixel stride ldup (concat slice). */

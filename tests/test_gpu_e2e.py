@@ -107,6 +107,28 @@ def test_train_step_fp32_matches_golden_and_fp64(tag):
     print(f"[{tag}] worst grad error ratio HIP/fp32-reference (both vs fp64) = {worst:.2f}")
 
 
+@pytest.mark.parametrize("tag", ["dc_c1", "dc_c3"])
+def test_input_gradient_fp32_matches_cpu_module(tag):
+    """dL/dx of the whole network (the reference module gives it through plain autograd): the HIP path's input gradient vs
+    the same module on the CPU (ATen, the reference's arithmetic), fp32, train mode; parameters keep their gradients too."""
+    from utils.metrics_DC import focal_dice_loss
+    model, g = build_model(tag, "train")
+    x, t = torch.from_numpy(g["train_x"]), torch.from_numpy(g["train_t"])
+    cpu = build_model(tag, "train")[0].train()
+    xc = x.clone().requires_grad_(True)
+    focal_dice_loss(cpu(xc), t, alpha=1.0, gamma=2.0, ratio=0.3).backward()
+    model = model.cuda().train()
+    xg = x.cuda().requires_grad_(True)
+    focal_dice_loss(model(xg), t.cuda(), alpha=1.0, gamma=2.0, ratio=0.3).backward()
+    assert xg.grad is not None and xg.grad.shape == x.shape
+    # the 2 x 2 bottleneck of the 32 x 32 goldens is ill-conditioned (see the module docstring): the bar is the parameter
+    # gradients' own bar of this file, a few times the fp32 reference's distance from fp64
+    e = rel_l2(xg.grad.cpu().numpy(), xc.grad.numpy())
+    print(f"[{tag}] rel-L2 of dL/dx, HIP fp32 vs CPU fp32: {e:.2e}")
+    assert e < 5e-2
+    assert float(model.enc1[0].weight.grad.abs().max()) > 0
+
+
 @pytest.mark.parametrize("tag", ["dc_c1"])
 def test_bf16_path_close_to_reference(tag):
     from utils.metrics_DC import focal_dice_loss

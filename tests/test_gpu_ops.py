@@ -340,6 +340,26 @@ def test_bn_relu_fwd_bwd(dtype, pool, case):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("cin", [1, 3])
+@pytest.mark.parametrize("shape", [(2, 24, 40, 1), (1, 64, 64, 2), (3, 10, 10, 1), (1, 8, 8, 16)])
+def test_first_conv_input_gradient(dtype, cin, shape):
+    """unetdc_conv3x3_first_dgrad: dL/dx of the first convolution vs torch autograd (ragged maps, dilation, a dilation
+    larger than the map: only the centre tap is in bounds)."""
+    n, h, w, d = shape
+    cout = 64
+    g = gen(31)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / 3
+    dy = G.quant(torch.randn(n, cout, h, w, generator=g), dtype)
+    xr = torch.zeros(n, cin, h, w, requires_grad=True)
+    dx_ref, = torch.autograd.grad(F.conv2d(xr, wt, None, padding=d, dilation=d), xr, dy)
+    dyv = G.to_nhwc(dy, dtype, ld=cout + 64, off=64)         # strided view
+    wd_, dx = wt.cuda().contiguous(), torch.full((n, cin, h, w), float("nan"), device="cuda")
+    call("unetdc_conv3x3_first_dgrad", dyv.data_ptr(), dyv.stride(0), wd_.data_ptr(), dx.data_ptr(), n, h, w, cin, cout, d,
+         G.DT[dtype], G.stream())
+    assert rel(dx.cpu(), dx_ref) < 2e-5            # fp32 accumulate of exactly representable operands on both sides
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("oc", [1, 2])
 def test_head_fwd_bwd(dtype, oc):
     n, h, w, c = 2, 16, 24, 64

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-end measurement set (GPU box, repo root):  tools/final_measure.sh <tag>     e.g. r02_final
 # Writes gpurun_out/<tag>_*; copy what should be judged into profiles/.
-tag=${1:-r02_final}
+tag=${1:-r03_final}
 export TMPDIR=/tmp
 set -e
 python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err                      # default run (with cpu_baseline)
@@ -17,6 +17,7 @@ python3 bench.py --arch unet --steps 20 --warmup 5 --no-cpu-baseline > gpurun_ou
 python3 bench.py --in-channels 3 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_bench_rgb.json 2>/dev/null
 python3 bench.py --dtype f32 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_train_f32.json 2>/dev/null
 UNETDC_DP_FORCE=1 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_bench_rccl1.json 2>/dev/null
+python3 bench.py --mode quantify --steps 10 --warmup 3 > gpurun_out/${tag}_bench_quantify.json 2>/dev/null
 ZERO=1 python3 tools/op_bench.py fwd 8 64 64 512 512 1 bf16 30 > gpurun_out/${tag}_zero_vs_random.txt 2>/dev/null
 python3 tools/op_bench.py fwd 8 64 64 512 512 1 bf16 30 >> gpurun_out/${tag}_zero_vs_random.txt 2>/dev/null
 ZERO=1 python3 tools/op_bench.py fwd 8 512 512 64 64 1 bf16 30 >> gpurun_out/${tag}_zero_vs_random.txt 2>/dev/null

@@ -38,6 +38,7 @@ SIGNATURES = {
     "unetdc_conv3x3_first_fwd": (I, [P, P, P, P, P, P, I, P, I, I, I, I, I, I, I, P]),
     "unetdc_conv3x3_first_wgrad_workspace": (L, [I, I, I, I, I]),
     "unetdc_conv3x3_first_wgrad": (I, [P, P, I, P, P, L, I, I, I, I, I, I, I, P]),
+    "unetdc_conv3x3_first_dgrad": (I, [P, I, P, P, I, I, I, I, I, I, I, P]),
     "unetdc_convT2x2_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, I, P]),
     "unetdc_convT2x2_dgrad": (I, [P, I, P, P, I, I, I, I, I, I, I, P]),
     "unetdc_convT2x2_wgrad_workspace": (L, [I, I, I, I, I, I]),

@@ -237,6 +237,12 @@ int unetdc_conv3x3_first_wgrad(const float* x_nchw, const void* dy, int lddy, fl
   return launch_first_wgrad(p, dw, workspace, (long)workspace_bytes, dtype, (hipStream_t)s);
 }
 
+int unetdc_conv3x3_first_dgrad(const void* dy, int lddy, const float* w, float* dx_nchw, int n, int h, int wd, int cin,
+                               int cout, int dilation, int dtype, unetdc_stream_t s) {
+  GEOM_CHECK(n, h, wd);
+  return launch_first_dgrad(dy, lddy, w, dx_nchw, n, h, wd, cin, cout, dilation, dtype, (hipStream_t)s);
+}
+
 int unetdc_convT2x2_fwd(const void* x, int ldx, const void* w_fwd, const float* bias, void* up, int ldup, int n,
                         int h, int w, int cin, int cout, int dtype, unetdc_stream_t s) {
   GEOM_CHECK(n, h, w);

@@ -312,6 +312,87 @@ long first_wgrad_workspace_bytes(long P, int Cin, int Cout) {
   return (nb > nr ? nb : nr) * Cin * 9 * Cout * 4;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Gradient with respect to the INPUT image of the first convolution (dL/dx of UNetDC.forward: the reference module supports
+// it through plain autograd, models/model_2.py:56-80; its training loops never ask for it):
+//   dx[n][ci][y][x] = sum_{co, tap} w[co][ci][tap] * dy[n][y - oy(tap)][x - ox(tap)][co]
+// HBM-bound like the forward: Cout/8 consecutive lanes own one pixel, each reads its 16-byte channel chunk of the (up to) 9
+// shifted dY pixels (neighbouring pixels re-read the same lines out of L1/L2), multiplies with the weights held in LDS as
+// [tap][ci][Cout] fp32 and the lanes of a pixel are summed with cross-lane shuffles; output NCHW fp32 like the input.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int CIN>
+__global__ __launch_bounds__(256) void first_dgrad_kernel(const FirstWgradParams p, float* __restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];     // [9][CIN][Cout]
+  constexpr int EPC = Chunk<T>::N;
+  const int tid = threadIdx.x;
+  const int G = p.Cout / EPC;               // lanes per pixel (power of two <= 64)
+  const int PPB = 256 / G;
+  for (int i = tid; i < 9 * CIN * p.Cout; i += 256) {
+    const int co = i % p.Cout, k = i / p.Cout, ci = k % CIN, tap = k / CIN;
+    wl[i] = reinterpret_cast<const float*>(p.part)[(co * CIN + ci) * 9 + tap];     // p.part carries the fp32 weight pointer here
+  }
+  __syncthreads();
+  const int g = tid % G, pl = tid / G;
+  const int HW = p.H * p.W;
+  const long P = (long)p.N * HW;
+  const T* __restrict__ dyg = reinterpret_cast<const T*>(p.dy);
+  for (long pb = (long)blockIdx.x * PPB; pb < P; pb += (long)gridDim.x * PPB) {
+    const long pix = pb + pl;
+    const bool ok = pix < P;
+    const long px = ok ? pix : 0;
+    const int n = (int)(px / HW), rem = (int)(px - (long)n * HW);
+    const int y = rem / p.W, x = rem - y * p.W;
+    float acc[CIN];
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) acc[ci] = 0.f;
+    for (int tap = 0; tap < 9; ++tap) {
+      const int iy = y - (tap / 3 - 1) * p.dil, ix = x - (tap % 3 - 1) * p.dil;      // the output pixel this tap came from
+      if (!ok || (unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.W) continue;
+      float v[EPC];
+      Chunk<T>::unpack(ld16(dyg + ((long)(n * p.H + iy) * p.W + ix) * p.lddy + g * EPC), v);
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci) {
+        const float* wr = wl + (tap * CIN + ci) * p.Cout + g * EPC;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[ci] = fmaf(v[e], wr[e], acc[ci]);
+      }
+    }
+    for (int o = 1; o < G; o <<= 1)
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci) acc[ci] += __shfl_xor(acc[ci], o, 64);
+    if (ok && g == 0) {
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci) dx[((long)(n * CIN + ci) * p.H + y) * p.W + x] = acc[ci];
+    }
+  }
+}
+
+int launch_first_dgrad(const void* dy, int lddy, const float* w, float* dx, int N, int H, int W, int Cin, int Cout, int dil,
+                       int dtype, hipStream_t stream) {
+  UNETDC_REQUIRE(dtype == UNETDC_F32 || dtype == UNETDC_BF16, "first_dgrad: bad dtype %d", dtype);
+  UNETDC_REQUIRE(dy && w && dx && N > 0 && H > 0 && W > 0 && dil >= 1, "first_dgrad: bad arguments");
+  UNETDC_REQUIRE(Cin == 1 || Cin == 3, "first_dgrad: Cin=%d unsupported (1 or 3)", Cin);
+  const int epc = dtype == UNETDC_BF16 ? 8 : 4;
+  const int G = Cout / epc;
+  UNETDC_REQUIRE(Cout % epc == 0 && G >= 1 && G <= 64 && (G & (G - 1)) == 0 && lddy % epc == 0 && lddy >= Cout,
+                 "first_dgrad: Cout=%d / lddy=%d unsupported", Cout, lddy);
+  FirstWgradParams p{};
+  p.dy = dy; p.part = const_cast<float*>(w); p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.lddy = lddy; p.dil = dil;
+  const long P = (long)N * H * W;
+  long nb = (P + (256 / G) * 4 - 1) / ((256 / G) * 4);
+  if (nb > 8192) nb = 8192;
+  if (nb < 1) nb = 1;
+  const size_t lds = (size_t)9 * Cin * Cout * 4;
+  if (dtype == UNETDC_BF16) {
+    if (Cin == 1) hipLaunchKernelGGL((first_dgrad_kernel<bf16_t, 1>), dim3((unsigned)nb), dim3(256), lds, stream, p, dx);
+    else hipLaunchKernelGGL((first_dgrad_kernel<bf16_t, 3>), dim3((unsigned)nb), dim3(256), lds, stream, p, dx);
+  } else {
+    if (Cin == 1) hipLaunchKernelGGL((first_dgrad_kernel<float, 1>), dim3((unsigned)nb), dim3(256), lds, stream, p, dx);
+    else hipLaunchKernelGGL((first_dgrad_kernel<float, 3>), dim3((unsigned)nb), dim3(256), lds, stream, p, dx);
+  }
+  return check_launch("first_dgrad_kernel");
+}
+
 int launch_first_wgrad(FirstWgradParams& p, float* dw, void* workspace, long workspace_bytes, int dtype,
                        hipStream_t stream) {
   UNETDC_REQUIRE(dtype == UNETDC_F32 || dtype == UNETDC_BF16, "first_wgrad: bad dtype %d", dtype);

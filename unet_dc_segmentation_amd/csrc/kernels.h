@@ -79,6 +79,8 @@ int launch_first_mfma_wgrad(FirstWgradParams& p, int* nblk_out, int dtype, hipSt
 long first_wgrad_workspace_bytes(long P, int Cin, int Cout);
 int launch_first_wgrad(FirstWgradParams& p, float* dw, void* workspace, long workspace_bytes, int dtype,
                        hipStream_t stream);
+int launch_first_dgrad(const void* dy, int lddy, const float* w, float* dx, int N, int H, int W, int Cin, int Cout, int dil,
+                       int dtype, hipStream_t stream);
 
 struct ApplyParams {
   const void* y; void* a; void* pooled;

@@ -43,13 +43,14 @@ FUSE_POOL_SKIP = os.environ.get("UNETDC_FUSE_POOL_SKIP", "0") == "1" and FUSE_CO
 # recomputes the activation the same way): dec1.3's normalisation pass and its 268 MB activation tensor disappear from the
 # training step.  UNETDC_FUSE_HEAD_BN=0: stand-alone pass (A/B switch)
 FUSE_HEAD_BN = os.environ.get("UNETDC_FUSE_HEAD_BN", "1") != "0" and FUSE_BN_BWD
-# Opt-in (UNETDC_SIDE_WGRAD=1): run the weight-gradient kernels, which hang off the backward critical
-# chain, on a side HIP stream.  Measured +1.3 ... +2.2 % on MI355X (round 3, same-box A/B: 11.96 / 12.03 -> 11.71 / 11.86
-# ms per step): the weight gradient of a stage fills the tail of that stage's dgrad -- NOT the HBM-bound BatchNorm passes:
-# both MFMA kernel families hold the whole register file (2 x 234-246 registers per SIMD lane), so a BatchNorm wave finds no
-# room beside them, and starting the weight gradient only behind its dgrad (so that it would run beside the next stage's
-# BatchNorm backward) gained nothing.  Off by default because overlapping kernels make per-kernel timings unattributable:
-# the roofline leg of bench.py then reads 0.38 instead of 0.49 for the dominant kernel (profiles/r03_side_stream_ab.txt).
+# Opt-in (UNETDC_SIDE_WGRAD=1): run the weight-gradient kernels, which hang off the backward critical chain, on a side
+# HIP stream.  Measured on MI355X in round 3 (same-box A/B, profiles/r03_side_stream_ab.txt): +1.3 ... +2.2 % with the 32x32x16
+# weight gradient, within noise since it moved to 16x16x32 MFMAs (11.41 vs 11.36 / 11.49 ms per step).  What overlapped was
+# the tail of a stage's dgrad, NOT the HBM-bound BatchNorm passes: both MFMA kernel families hold the whole register file
+# (2 x 234-246 registers per SIMD lane), so a BatchNorm wave finds no room beside them; limiting the weight gradient to one
+# workgroup per CU, or starting it only behind its stage's dgrad, lost more than the overlap gave.  Off by default also
+# because overlapping kernels make per-kernel timings unattributable (bench.py's roofline leg then reads 0.38 instead of
+# 0.49 for the dominant kernel).
 SIDE_WGRAD = os.environ.get("UNETDC_SIDE_WGRAD", "0") == "1"
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -306,7 +307,7 @@ class UNetEngine:
         if x.dtype != torch.float32:
             x = x.float()
         x = x.contiguous()
-        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.params)
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.params))
         if model.training and not needs_grad:
             # train-mode BatchNorm under no_grad: same arithmetic, nothing saved
             return self.forward(x, train=True)
@@ -567,6 +568,15 @@ class UNetEngine:
             assert hi - lo == sum(q.numel() for q in ps), "gradient ranges must be contiguous in the flat buffer"
             hook(flat, lo, hi)
 
+    def input_grad(self):
+        """dL/dx [N, C_in, H, W] fp32 of the backward that has just been enqueued: the first convolution's dgrad from the
+        gradient of its output (kept in the stage's dy buffer).  Only computed when the input requires a gradient."""
+        st = self.stages[("enc1", 0)]
+        dx = torch.empty(self.N, self.cin, self.H, self.W, device=self.device, dtype=torch.float32)
+        call("unetdc_conv3x3_first_dgrad", st.dy.data_ptr(), st.dy.stride(0), st.conv.weight.data_ptr(), dx.data_ptr(), self.N,
+             self.H, self.W, self.cin, st.cout, st.dil, self.dt, _stream())
+        return dx
+
     def backward(self, dprobs, probs):
         """dprobs, probs: [N, OC, H, W] fp32.  Returns the flat fp32 gradient buffer (parameters() order)."""
         self._ensure_grad_bufs()
@@ -667,4 +677,5 @@ class _UNetFunction(torch.autograd.Function):
         grads = []
         for p, o in zip(eng.params, eng.poffs):
             grads.append(flat[o:o + p.numel()].view_as(p) if p.requires_grad else None)
-        return (None, None, *grads)
+        dx = eng.input_grad() if ctx.needs_input_grad[0] else None
+        return (dx, None, *grads)
