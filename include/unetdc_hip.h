@@ -169,6 +169,19 @@ int unetdc_bn_relu_bwd(const void* dskip, int ldskip, const void* dpool, int ldp
                        const float* gamma, void* dy, int lddy, float* dgamma, float* dbeta, float* dbias,
                        void* workspace, int64_t workspace_bytes, const float* pre_parts, int pre_nparts, int n, int h,
                        int w, int c, int dtype, unetdc_stream_t s);
+/* BatchNorm with FROZEN statistics under autograd -- model.eval() with gradients enabled, i.e. fine-tuning with fixed
+ * running statistics, which the reference module supports through plain autograd (nn.BatchNorm2d in eval mode,
+ * models/model_2.py:45,52): unetdc_bn_frozen_affine fills scale / shift / mean / rstd from the running buffers (the conv bias
+ * is added by the conv epilogue as in training), the forward then uses the training-path kernels; unetdc_bn_relu_bwd_frozen is
+ * unetdc_bn_relu_bwd for that case: dy = gamma * rstd * dyhat (no batch terms), dgamma = sum dyhat * xhat, dbeta = sum dyhat,
+ * dbias = sum dy. */
+int unetdc_bn_frozen_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                            float eps, float* scale, float* shift, float* mean, float* rstd, int c, unetdc_stream_t s);
+int unetdc_bn_relu_bwd_frozen(const void* dskip, int ldskip, const void* dpool, int ldpool, const void* y, int ldy,
+                              const float* scale, const float* shift, const float* mean, const float* rstd,
+                              const float* gamma, void* dy, int lddy, float* dgamma, float* dbeta, float* dbias,
+                              void* workspace, int64_t workspace_bytes, const float* pre_parts, int pre_nparts, int n, int h,
+                              int w, int c, int dtype, unetdc_stream_t s);
 /* Pooled encoder stage (its activation gradient = dskip + scatter of dpool to the window arg-max): the BatchNorm-backward
  * sums are linear in the gradient, so the dskip part may come from the epilogue of the kernel that wrote dskip --
  * unetdc_conv3x3_dgrad_bnstats on the [pixels, 2C] concat gradient with per-column constants that are neutral for the

@@ -129,6 +129,41 @@ def test_input_gradient_fp32_matches_cpu_module(tag):
     assert float(model.enc1[0].weight.grad.abs().max()) > 0
 
 
+@pytest.mark.parametrize("tag", ["dc_c1", "plain_c3"])
+def test_eval_mode_autograd_frozen_batchnorm_fp32(tag):
+    """model.eval() with gradients enabled (fine-tuning with frozen BatchNorm statistics; the reference module supports it
+    through plain autograd): probabilities equal the no_grad eval forward, parameter and input gradients match the same
+    module on the CPU (ATen) within the bar of the train-mode test, running statistics stay untouched."""
+    from utils.metrics_DC import focal_dice_loss
+    model, g = build_model(tag, "eval")
+    x, t = torch.from_numpy(g["train_x"]), torch.from_numpy(g["train_t"])
+    cpu = build_model(tag, "eval")[0].eval()
+    xc = x.clone().requires_grad_(True)
+    pc = cpu(xc)
+    focal_dice_loss(pc, t, alpha=1.0, gamma=2.0, ratio=0.3).backward()
+    model = model.cuda().eval()
+    before = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}
+    with torch.no_grad():
+        p_ng = model(x.cuda()).cpu()
+    xg = x.cuda().requires_grad_(True)
+    p = model(xg)
+    focal_dice_loss(p, t.cuda(), alpha=1.0, gamma=2.0, ratio=0.3).backward()
+    assert float((p.detach().cpu() - pc.detach()).abs().max()) < 1e-5
+    assert float((p.detach().cpu() - p_ng).abs().max()) < 1e-5        # training-path kernels vs folded-BatchNorm inference kernels
+    for k, v in model.state_dict().items():
+        if k in before:
+            assert torch.equal(v, before[k]), k
+    worst = 0.0
+    for (k, pg), pcpu in zip(model.named_parameters(), cpu.parameters()):
+        ref = pcpu.grad.double()
+        e = float((pg.grad.cpu().double() - ref).norm()) / max(float(ref.norm()), 1e-12)
+        worst = max(worst, e)
+        assert e < 2e-3, (k, e)
+    e = rel_l2(xg.grad.cpu().numpy(), xc.grad.numpy())
+    print(f"[{tag}] eval-mode autograd: worst parameter-gradient rel-L2 {worst:.2e}, dL/dx rel-L2 {e:.2e}")
+    assert e < 2e-3
+
+
 @pytest.mark.parametrize("tag", ["dc_c1"])
 def test_bf16_path_close_to_reference(tag):
     from utils.metrics_DC import focal_dice_loss

@@ -48,6 +48,8 @@ SIGNATURES = {
     "unetdc_bn_relu_apply": (I, [P, I, P, P, P, I, P, I, I, I, I, I, I, P]),
     "unetdc_bn_relu_bwd_workspace": (L, [I, I, I, I, I, I]),
     "unetdc_bn_relu_bwd": (I, [P, I, P, I, P, I, P, P, P, P, P, P, I, P, P, P, P, L, P, I, I, I, I, I, I, P]),
+    "unetdc_bn_frozen_affine": (I, [P, P, P, P, F, P, P, P, P, I, P]),
+    "unetdc_bn_relu_bwd_frozen": (I, [P, I, P, I, P, I, P, P, P, P, P, P, I, P, P, P, P, L, P, I, I, I, I, I, I, P]),
     "unetdc_bn_relu_bwd_pool_split": (I, [P, I, P, I, P, I, P, P, P, P, P, P, I, P, P, P, P, L, P, I, I, I, I, I, I, I, I, P]),
     "unetdc_parts_colsum": (I, [P, I, I, I, I, P, P]),
     "unetdc_conv3x3_dgrad_bnstats": (I, [P, I, P, P, I, P, I, P, P, P, P, P, L, P, I, I, I, I, I, I, I, P]),

@@ -322,6 +322,24 @@ int unetdc_bn_relu_bwd(const void* dskip, int ldskip, const void* dpool, int ldp
                        (hipStream_t)s);
 }
 
+int unetdc_bn_frozen_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                            float eps, float* scale, float* shift, float* mean, float* rstd, int c, unetdc_stream_t s) {
+  return launch_bn_frozen_affine(gamma, beta, running_mean, running_var, eps, scale, shift, mean, rstd, c, (hipStream_t)s);
+}
+
+int unetdc_bn_relu_bwd_frozen(const void* dskip, int ldskip, const void* dpool, int ldpool, const void* y, int ldy,
+                              const float* scale, const float* shift, const float* mean, const float* rstd,
+                              const float* gamma, void* dy, int lddy, float* dgamma, float* dbeta, float* dbias,
+                              void* workspace, int64_t workspace_bytes, const float* pre_parts, int pre_nparts, int n, int h,
+                              int w, int c, int dtype, unetdc_stream_t s) {
+  GEOM_CHECK(n, h, w);
+  BnBwdParams p{};
+  p.dskip = dskip; p.dpool = dpool; p.y = y; p.dy = dy; p.scale = scale; p.shift = shift; p.mean = mean; p.rstd = rstd;
+  p.N = n; p.H = h; p.W = w; p.C = c; p.lds = ldskip; p.ldp = ldpool; p.ldy = ldy; p.lddy = lddy;
+  return launch_bn_bwd(p, gamma, dgamma, dbeta, dbias, workspace, (long)workspace_bytes, pre_parts, pre_nparts, dtype,
+                       (hipStream_t)s, true);
+}
+
 int unetdc_bn_relu_bwd_pool_split(const void* dskip, int ldskip, const void* dpool, int ldpool, const void* y, int ldy,
                                   const float* scale, const float* shift, const float* mean, const float* rstd,
                                   const float* gamma, void* dy, int lddy, float* dgamma, float* dbeta, float* dbias,

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               double count, const float* __restrict__ gamma,
                                                               const float* __restrict__ rstd, float* dgamma,
                                                               float* dbeta, float* dbias, float* k1, float* k2,
-                                                              float* k3, int C) {
+                                                              float* k3, int C, int frozen) {
   const int c = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
   if (c >= C) return;
   double s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -310,6 +310,14 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   dgamma[c] = (float)s2;
   dbeta[c] = (float)s1;
   k1[c] = (float)a;
+  if (frozen) {
+    // statistics that do not depend on the batch (eval-mode BatchNorm under autograd: running mean / variance): the
+    // normalisation is a fixed per-channel affine map, dy = gamma * rstd * dyhat, and the conv bias sees sum(dy)
+    k2[c] = 0.f;
+    k3[c] = 0.f;
+    if (dbias) dbias[c] = (float)(a * s1);
+    return;
+  }
   k2[c] = (float)(a * s1 / count);
   k3[c] = (float)(a * s2 / count);
   if (dbias) dbias[c] = (float)(-(a * s2 / count) * s3);
@@ -689,6 +697,29 @@ int launch_bn_finalize(const float* parts, int nparts, long count, const float* 
   return check_launch("bn_finalize_kernel");
 }
 
+// BatchNorm with FROZEN statistics under autograd (model.eval() with gradients enabled): the training-path kernels run with
+// mean / rstd taken from the running buffers instead of the batch; the conv bias is added by the conv epilogue as in training
+__global__ void bn_frozen_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                        const float* __restrict__ rm, const float* __restrict__ rv, float eps, float* scale,
+                                        float* shift, float* mean, float* rstd, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float r = 1.f / sqrtf(rv[c] + eps);
+  const float sc = gamma[c] * r;
+  scale[c] = sc;
+  shift[c] = beta[c] - rm[c] * sc;
+  mean[c] = rm[c];
+  rstd[c] = r;
+}
+
+int launch_bn_frozen_affine(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* scale,
+                            float* shift, float* mean, float* rstd, int C, hipStream_t stream) {
+  UNETDC_REQUIRE(gamma && beta && rm && rv && scale && shift && mean && rstd, "bn_frozen_affine: null pointer");
+  hipLaunchKernelGGL(bn_frozen_affine_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, gamma, beta, rm, rv, eps, scale, shift,
+                     mean, rstd, C);
+  return check_launch("bn_frozen_affine_kernel");
+}
+
 int launch_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv,
                           const float* conv_bias, float eps, float* scale, float* shift, int C, hipStream_t stream) {
   UNETDC_REQUIRE(gamma && beta && rm && rv && scale && shift, "bn_eval_affine: null pointer");
@@ -772,7 +803,7 @@ int launch_bn_bwd_reduce_only(BnBwdParams& p, float* parts, long parts_floats, i
 }
 
 int launch_bn_bwd(BnBwdParams& p, const float* gamma, float* dgamma, float* dbeta, float* dbias, void* workspace,
-                  long workspace_bytes, const float* pre_parts, int pre_nparts, int dtype, hipStream_t stream) {
+                  long workspace_bytes, const float* pre_parts, int pre_nparts, int dtype, hipStream_t stream, bool frozen) {
   const int epc = dtype == UNETDC_BF16 ? 8 : 4;
   UNETDC_REQUIRE(dtype == UNETDC_F32 || dtype == UNETDC_BF16, "bn_bwd: bad dtype %d", dtype);
   UNETDC_REQUIRE(p.y && p.dy && (p.dskip || p.dpool), "bn_bwd: null tensor");
@@ -814,7 +845,7 @@ int launch_bn_bwd(BnBwdParams& p, const float* gamma, float* dgamma, float* dbet
   if (rc != UNETDC_OK) return rc;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 7) / 8), dim3(256), 0, stream, rp, rows, p.C, 0,
                      (const float*)nullptr, 0, (double)p.N * p.H * p.W, gamma, p.rstd, dgamma, dbeta, dbias, k, k + p.C,
-                     k + 2 * p.C, p.C);
+                     k + 2 * p.C, p.C, frozen ? 1 : 0);
   rc = check_launch("bn_bwd_finalize_kernel");
   if (rc != UNETDC_OK) return rc;
   const long items = Q * cpp;
@@ -869,7 +900,7 @@ int launch_bn_bwd_pool_split(BnBwdParams& p, const float* gamma, float* dgamma, 
   rc = reduce_parts(skip_parts, skip_rows, 3 * skip_cs, &sp, &srows, stream, 512);    // > 512 rows: one stage into the 64 spare rows
   if (rc != UNETDC_OK) return rc;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 7) / 8), dim3(256), 0, stream, sp, srows, skip_cs, skip_c0, rp, rows,
-                     (double)p.N * p.H * p.W, gamma, p.rstd, dgamma, dbeta, dbias, k, k + p.C, k + 2 * p.C, p.C);
+                     (double)p.N * p.H * p.W, gamma, p.rstd, dgamma, dbeta, dbias, k, k + p.C, k + 2 * p.C, p.C, 0);
   rc = check_launch("bn_bwd_finalize_kernel");
   if (rc != UNETDC_OK) return rc;
   const long items = Q * cpp;

@@ -111,7 +111,10 @@ int launch_bn_eval_affine(const float* gamma, const float* beta, const float* rm
 int launch_apply(ApplyParams& p, int dtype, hipStream_t stream);
 long bn_bwd_workspace_bytes(int N, int H, int W, int C, int pooled, int dtype);
 int launch_bn_bwd(BnBwdParams& p, const float* gamma, float* dgamma, float* dbeta, float* dbias, void* workspace,
-                  long workspace_bytes, const float* pre_parts, int pre_nparts, int dtype, hipStream_t stream);
+                  long workspace_bytes, const float* pre_parts, int pre_nparts, int dtype, hipStream_t stream,
+                  bool frozen = false);
+int launch_bn_frozen_affine(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* scale,
+                            float* shift, float* mean, float* rstd, int C, hipStream_t stream);
 int launch_bn_bwd_pool_split(BnBwdParams& p, const float* gamma, float* dgamma, float* dbeta, float* dbias, void* workspace,
                              long workspace_bytes, const float* skip_parts, int skip_rows, int skip_cs, int skip_c0, int dtype,
                              hipStream_t stream);

@@ -311,14 +311,13 @@ class UNetEngine:
         if model.training and not needs_grad:
             # train-mode BatchNorm under no_grad: same arithmetic, nothing saved
             return self.forward(x, train=True)
-        if not model.training and needs_grad:
-            raise _lib.UnetdcError("autograd through eval-mode BatchNorm is not implemented in the HIP path; "
-                                   "call under torch.no_grad() or switch to train()")
         if needs_grad:
-            return _UNetFunction.apply(x, self, *self.params)
+            # eval mode with gradients enabled (fine-tuning with frozen BatchNorm statistics): the training-path kernels with
+            # mean / variance taken from the running buffers, which stay untouched
+            return _UNetFunction.apply(x, self, not model.training, *self.params)
         return self.forward(x, train=False)
 
-    def _stage_fwd(self, st, xin, dst, train, pooled=None, apply=True):
+    def _stage_fwd(self, st, xin, dst, train, pooled=None, apply=True, frozen=False):
         """conv -> BN -> ReLU.  xin: [npix, cin] view (or the NCHW image for the first stage);
         dst: [npix, cout] view receiving the activation; pooled: optional [npix/4, cout] view;
         apply=False (train mode only): stop after the batch statistics -- the consumer normalises on load."""
@@ -340,11 +339,16 @@ class UNetEngine:
                 st.stat_rows = _lib.load().unetdc_last_stats_rows()     # rows that carry data (<= the sizing bound)
             track = bn.track_running_stats and bn.running_mean is not None
             mom = BN_MOMENTUM if bn.momentum is None else bn.momentum
-            call("unetdc_bn_finalize", st.stats.data_ptr(), st.stat_rows, st.npix, bn.weight.data_ptr(),
-                 bn.bias.data_ptr(), bn.eps, mom, _ptr(bn.running_mean) if track else None,
-                 _ptr(bn.running_var) if track else None, st.scale.data_ptr(), st.shift.data_ptr(),
-                 st.mean.data_ptr(), st.rstd.data_ptr(), st.cout, s)
-            if track:
+            if frozen and track:
+                call("unetdc_bn_frozen_affine", bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                     bn.running_var.data_ptr(), bn.eps, st.scale.data_ptr(), st.shift.data_ptr(), st.mean.data_ptr(),
+                     st.rstd.data_ptr(), st.cout, s)
+            else:                                              # (eval mode without running buffers = batch statistics, as nn.BatchNorm2d)
+                call("unetdc_bn_finalize", st.stats.data_ptr(), st.stat_rows, st.npix, bn.weight.data_ptr(),
+                     bn.bias.data_ptr(), bn.eps, mom, _ptr(bn.running_mean) if track and not frozen else None,
+                     _ptr(bn.running_var) if track and not frozen else None, st.scale.data_ptr(), st.shift.data_ptr(),
+                     st.mean.data_ptr(), st.rstd.data_ptr(), st.cout, s)
+            if track and not frozen:
                 self._nbt.append(bn.num_batches_tracked)       # incremented together at the end of forward()
             if apply:
                 call("unetdc_bn_relu_apply", y.data_ptr(), y.stride(0), st.scale.data_ptr(), st.shift.data_ptr(),
@@ -366,8 +370,11 @@ class UNetEngine:
                 call("unetdc_bn_relu_apply", dst.data_ptr(), dst.stride(0), None, None, None, 0,
                      pooled.data_ptr(), pooled.stride(0), N, h, w, st.cout, self.dt, s)
 
-    def forward(self, x, train):
+    def forward(self, x, train, frozen=False):
+        """train: the training-path kernels (batch statistics, everything saved for backward); frozen (with train): BatchNorm
+        statistics from the running buffers instead of the batch (eval mode under autograd)."""
         self.generation += 1               # every forward overwrites the activation buffers
+        self._frozen = bool(frozen)
         self.weights.ensure(need_dgrad=train)
         self._nbt = []
         s = _stream()
@@ -376,12 +383,12 @@ class UNetEngine:
         hin = x
         for l, name in enumerate(ENCODER):
             c = widths[l]
-            self._stage_fwd(self.stages[(name, 0)], hin, self.a0[name], train)
+            self._stage_fwd(self.stages[(name, 0)], hin, self.a0[name], train, frozen=frozen)
             skip = self.cat[l + 1][:, c:]
-            self._stage_fwd(self.stages[(name, 3)], self.a0[name], skip, train, pooled=self.pool[l + 1])
+            self._stage_fwd(self.stages[(name, 3)], self.a0[name], skip, train, pooled=self.pool[l + 1], frozen=frozen)
             hin = self.pool[l + 1]
-        self._stage_fwd(self.stages[("bottleneck", 0)], hin, self.a0["bottleneck"], train)
-        self._stage_fwd(self.stages[("bottleneck", 3)], self.a0["bottleneck"], self.a3["bottleneck"], train)
+        self._stage_fwd(self.stages[("bottleneck", 0)], hin, self.a0["bottleneck"], train, frozen=frozen)
+        self._stage_fwd(self.stages[("bottleneck", 3)], self.a0["bottleneck"], self.a3["bottleneck"], train, frozen=frozen)
         hin = self.a3["bottleneck"]
         for lvl in (4, 3, 2, 1):
             u = self.up[lvl]
@@ -393,8 +400,8 @@ class UNetEngine:
                  u["mod"].bias.data_ptr(), upv.data_ptr(), upv.stride(0), N, h, w, u["cin"], c, self.dt, s)
             name = f"dec{lvl}"
             head_norm = train and FUSE_HEAD_BN and lvl == 1          # dec1.3: normalised by the head while loading
-            self._stage_fwd(self.stages[(name, 0)], self.cat[lvl], self.a0[name], train)
-            self._stage_fwd(self.stages[(name, 3)], self.a0[name], self.a3[name], train, apply=not head_norm)
+            self._stage_fwd(self.stages[(name, 0)], self.cat[lvl], self.a0[name], train, frozen=frozen)
+            self._stage_fwd(self.stages[(name, 3)], self.a0[name], self.a3[name], train, apply=not head_norm, frozen=frozen)
             hin = self.a3[name]
         probs = torch.empty(N, self.oc, self.H, self.W, device=self.device, dtype=torch.float32)
         oc = self.model.out_conv
@@ -477,7 +484,7 @@ class UNetEngine:
         dy = st.dy
         ws, wsb = self.workspace.data_ptr(), self.ws_bytes
         pre = (st.bwd_parts.data_ptr(), st.bwd_nparts) if (st.bwd_nparts and dpool is None) else (None, 0)
-        if dpool is not None and dskip is not None and getattr(st, "skip_rows", 0):
+        if dpool is not None and dskip is not None and getattr(st, "skip_rows", 0) and not self._frozen:
             # the skip part of the sums came out of the decoder dgrad that wrote dskip (see FUSE_POOL_SKIP)
             call("unetdc_bn_relu_bwd_pool_split", dskip.data_ptr(), dskip.stride(0), dpool.data_ptr(), dpool.stride(0),
                  st.y.data_ptr(), st.y.stride(0), st.scale.data_ptr(), st.shift.data_ptr(), st.mean.data_ptr(),
@@ -492,7 +499,7 @@ class UNetEngine:
         self._stage_bwd_rest(st, flat, lvl, dx_out, fuse_prev, colsum, skip_for, dy, ws, wsb, N, h, w, s)
 
     def _bn_relu_bwd_plain(self, st, flat, dskip, dpool, dy, pre, ws, wsb, N, h, w, s):
-        call("unetdc_bn_relu_bwd", _ptr(dskip), dskip.stride(0) if dskip is not None else 0,
+        call("unetdc_bn_relu_bwd_frozen" if self._frozen and st.bn.running_mean is not None else "unetdc_bn_relu_bwd", _ptr(dskip), dskip.stride(0) if dskip is not None else 0,
              _ptr(dpool), dpool.stride(0) if dpool is not None else 0, st.y.data_ptr(), st.y.stride(0),
              st.scale.data_ptr(), st.shift.data_ptr(), st.mean.data_ptr(), st.rstd.data_ptr(),
              st.bn.weight.data_ptr(), dy.data_ptr(), dy.stride(0), self._gview(flat, st.bn.weight).data_ptr(),
@@ -522,7 +529,7 @@ class UNetEngine:
                      dx_out.data_ptr(), dx_out.stride(0), *self._bnstats_args(fuse_prev), N, h, w, st.cin, st.cout,
                      st.dil, self.dt, s)
                 fuse_prev.bwd_nparts = self._np.value
-            elif dx_out is not None and colsum is not None and skip_for is not None and FUSE_POOL_SKIP:
+            elif dx_out is not None and colsum is not None and skip_for is not None and FUSE_POOL_SKIP and not self._frozen:
                 # dx_out = gradient of cat([up, skip]): one epilogue gives the column sums of its first half (the up-conv
                 # bias gradient) AND the skip part of the encoder stage's BatchNorm-backward sums
                 enc, combo = skip_for
@@ -651,8 +658,8 @@ class _UNetFunction(torch.autograd.Function):
     """Autograd boundary: one node for the whole network (forward kernels / backward kernels)."""
 
     @staticmethod
-    def forward(ctx, x, engine, *params):
-        probs = engine.forward(x, train=True)
+    def forward(ctx, x, engine, frozen, *params):
+        probs = engine.forward(x, train=True, frozen=frozen)
         ctx.engine = engine
         ctx.generation = engine.generation
         # x (read by the first layer's weight gradient) and probs (read by the head backward) go through autograd's
@@ -678,4 +685,4 @@ class _UNetFunction(torch.autograd.Function):
         for p, o in zip(eng.params, eng.poffs):
             grads.append(flat[o:o + p.numel()].view_as(p) if p.requires_grad else None)
         dx = eng.input_grad() if ctx.needs_input_grad[0] else None
-        return (dx, None, *grads)
+        return (dx, None, None, *grads)
