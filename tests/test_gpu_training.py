@@ -56,10 +56,10 @@ def test_thirty_training_steps_bf16_tracks_fp32_and_cpu_reference():
     """HIP bf16 vs HIP fp32 vs the ATen-CPU fp32 module (the reference's own arithmetic) over 30 Adam steps on 4 fixed
     seeded batches of 4 x 1 x 128 x 128 droplet tiles.
 
-    Bands: fp32 HIP vs CPU fp32 -- the first 5 losses within 1e-4 relative (same arithmetic up to summation order), all
-    30 within 2 % (training amplifies rounding differences: two fp32 evaluation orders of the same network drift apart
-    at this rate too); bf16 vs fp32 HIP -- every loss within 5 %, the mean gap below 2 %; all three end below 80 % of
-    where they started."""
+    Bands (measured on MI355X: 3.0e-5 / 7.0e-4 / 1.3e-3 / 4.0e-4): fp32 HIP vs CPU fp32 -- the first 5 losses within 2e-4
+    relative (same arithmetic up to summation order), all 30 within 5e-3 (training amplifies rounding differences: two fp32
+    evaluation orders of the same network drift apart at this rate too); bf16 vs fp32 HIP -- every loss within 1e-2, the
+    mean gap below 4e-3; all three end below 80 % of where they started."""
     xs, ts = _batches()
     l_cpu, _ = _run("cpu", "f32", xs, ts, fused=False)
     l_f32, _ = _run("cuda", "f32", xs, ts, fused=True)
@@ -72,10 +72,10 @@ def test_thirty_training_steps_bf16_tracks_fp32_and_cpu_reference():
           f"bf16 vs fp32 HIP: max {rel(l_bf, l_f32).max():.2e}, mean {rel(l_bf, l_f32).mean():.2e}")
     for l in (l_cpu, l_f32, l_bf):
         assert np.all(np.isfinite(l)) and l[-4:].mean() < 0.8 * l[:4].mean()
-    assert rel(l_f32, l_cpu)[:5].max() < 1e-4
-    assert rel(l_f32, l_cpu).max() < 2e-2
-    assert rel(l_bf, l_f32).max() < 5e-2
-    assert rel(l_bf, l_f32).mean() < 2e-2
+    assert rel(l_f32, l_cpu)[:5].max() < 2e-4
+    assert rel(l_f32, l_cpu).max() < 5e-3
+    assert rel(l_bf, l_f32).max() < 1e-2
+    assert rel(l_bf, l_f32).mean() < 4e-3
     # the bf16-trained weights, evaluated by the fp32 CPU oracle, segment the training tiles as well as they did on the device
     sd = {k: v.detach().cpu().clone() for k, v in m_bf.state_dict().items()}
     m_bf.eval()
