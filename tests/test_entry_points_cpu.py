@@ -256,6 +256,26 @@ def test_fused_adam_cpu_formulas_match_torch():
         assert torch.allclose(pa, pb, rtol=1e-6, atol=1e-8)
 
 
+def test_module_copies_and_pickles_without_its_engines():
+    """deepcopy / pickle of the drop-in module: parameters and buffers travel, device-side engines and hooks do not."""
+    import copy
+    import io
+    from models.model_2 import UNetDC
+    m = UNetDC(1, 1)
+    m._engines[("fake", (1, 1, 16, 16))] = object()         # stands in for an engine with device buffers
+    m._weights = object()
+    m.grad_ready_hook = lambda *a: None
+    c = copy.deepcopy(m)
+    assert c._engines == {} and c._weights is None and c.grad_ready_hook is None and c._engine is None
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), c.state_dict().values()))
+    buf = io.BytesIO()
+    torch.save(m.state_dict(), buf)                        # the reference's checkpoint format (train_DC_focal.py:326)
+    buf.seek(0)
+    c.load_state_dict(torch.load(buf, weights_only=True))
+    x = torch.rand(1, 1, 16, 16)
+    assert torch.equal(m.eval()(x), c.eval()(x))
+
+
 def test_nearest_resize_restates_cv2_rule():
     """cv2.resize(..., INTER_NEAREST) picks source index min(floor(d * src / dst), src - 1) (known answers computed by
     hand: 4 -> 6 gives 0,0,1,2,2,3; 5 -> 2 gives 0,2); identity at equal size."""

@@ -59,6 +59,28 @@ def resize_to_input_device(img_u8, size):
 
 MAX_ELEMENT = 128          # csrc/preprocess.hip PP_MAXK: the structuring element and its halo must fit one LDS tile
 
+_pinned = {}               # nbytes -> ring of (pinned uint8 buffer, event of the last upload out of it)
+_PIN_RING = 4
+
+
+def _upload(img_u8_host, device):
+    """Decoded image (numpy uint8) -> device tensor through a small ring of pinned staging buffers: the copy into pinned
+    memory is host work that overlaps the device's work on the previous image, and the upload itself is asynchronous (a
+    pageable-memory .to(device) blocks the host for every image of a batch)."""
+    a = np.ascontiguousarray(img_u8_host)
+    ring = _pinned.setdefault(a.nbytes, {"bufs": [], "next": 0})
+    if len(ring["bufs"]) < _PIN_RING:
+        ring["bufs"].append([torch.empty(a.nbytes, dtype=torch.uint8).pin_memory(), None])
+    slot = ring["bufs"][ring["next"] % len(ring["bufs"])]
+    ring["next"] += 1
+    if slot[1] is not None:
+        slot[1].synchronize()                       # the upload that last used this buffer has finished
+    slot[0].copy_(torch.from_numpy(a).reshape(-1))
+    t = slot[0].to(device, non_blocking=True).view(a.shape)
+    slot[1] = torch.cuda.Event()
+    slot[1].record()
+    return t
+
 
 def preprocess_device(img_u8_host, radius, size, device="cuda"):
     """numpy [H, W, 3] uint8 (a decoded image) -> network input [3, size, size] float32 on the device.
@@ -67,7 +89,5 @@ def preprocess_device(img_u8_host, radius, size, device="cuda"):
     on the device."""
     if int(radius) > MAX_ELEMENT:
         from utils.data_loader import rolling_ball_correction_rgb
-        t = torch.from_numpy(np.ascontiguousarray(rolling_ball_correction_rgb(img_u8_host, int(radius)))).to(device)
-        return resize_to_input_device(t, size)
-    t = torch.from_numpy(np.ascontiguousarray(img_u8_host)).to(device)
-    return resize_to_input_device(rolling_ball_device(t, radius), size)
+        return resize_to_input_device(_upload(rolling_ball_correction_rgb(img_u8_host, int(radius)), device), size)
+    return resize_to_input_device(rolling_ball_device(_upload(img_u8_host, device), radius), size)

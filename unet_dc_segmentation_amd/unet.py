@@ -90,6 +90,14 @@ class _UNetFamily(nn.Module):
         self._engines[key] = eng
         return eng
 
+    def __getstate__(self):
+        """copy.deepcopy / pickling (torch.save(model)) carry the module, not the device-side engines: activation buffers,
+        packed weight images and the data-parallel hooks are rebuilt on the first forward of the copy."""
+        state = dict(self.__dict__)
+        state["_engines"], state["_weights"] = {}, None
+        state["grad_ready_hook"], state["grad_sync_finish"] = None, None
+        return state
+
     @property
     def _engine(self):
         """The most recently used engine (None before the first HIP forward)."""
