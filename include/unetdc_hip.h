@@ -104,6 +104,19 @@ int unetdc_last_stats_rows(void);
 int unetdc_conv3x3_fwd(const void* x, int ldx, const void* w_fwd, const float* bias, const float* scale,
                        const float* shift, void* y, int ldy, float* stats_part, int n, int h, int w, int cin,
                        int cout, int dilation, int dtype, unetdc_stream_t s);
+/* "bnin" forms (round 3): the convolution / weight gradient are fed from the RAW conv output of the stage in front of them and
+ * apply that stage's BatchNorm + ReLU -- relu(in_scale * x + in_shift), models/model_2.py:45-46, rounded through the storage
+ * type like a stored activation -- once per staged tile in LDS: the stand-alone unetdc_bn_relu_apply pass of that stage and
+ * its activation tensor disappear; outputs are bit-identical to the two-pass form.  bf16 only, shapes the persistent lattice
+ * kernel (64-channel output form) and the tap-split ring weight gradient take: ask unetdc_conv3x3_bnin_supported first.
+ * fwd: statistics mode only (training); in_scale / in_shift [cin] are the producing stage's batch scale / shift. */
+int unetdc_conv3x3_bnin_supported(int n, int h, int w, int cin, int cout, int dilation, int dtype);
+int unetdc_conv3x3_fwd_bnin(const void* x_raw, int ldx, const float* in_scale, const float* in_shift, const void* w_fwd,
+                            const float* bias, void* y, int ldy, float* stats_part, int n, int h, int w, int cin, int cout,
+                            int dilation, int dtype, unetdc_stream_t s);
+int unetdc_conv3x3_wgrad_bnin(const void* x_raw, int ldx, const float* in_scale, const float* in_shift, const void* dy,
+                              int lddy, float* dw, void* workspace, int64_t workspace_bytes, int n, int h, int w, int cin,
+                              int cout, int dilation, int dtype, unetdc_stream_t s);
 /* dx = conv_transpose(dy): autograd of the above w.r.t. its input (dx has cin channels). */
 int unetdc_conv3x3_dgrad(const void* dy, int lddy, const void* w_dgrad, void* dx, int lddx, int n, int h, int w,
                          int cin, int cout, int dilation, int dtype, unetdc_stream_t s);

@@ -339,6 +339,53 @@ def test_bn_relu_fwd_bwd(dtype, pool, case):
         np.testing.assert_allclose(cs.cpu().numpy(), spv[:, 0, c:].double().sum(0).float().cpu().numpy(), rtol=1e-6)
 
 
+@pytest.mark.parametrize("case", [(2, 256, 256, 64, 64, 1), (3, 512, 256, 64, 64, 1), (2, 64, 256, 64, 64, 2), (2, 96, 192, 64, 64, 1),
+                                  (2, 128, 128, 128, 64, 1)])
+def test_conv_and_wgrad_fed_from_raw_output_normalise_on_load(case):
+    """unetdc_conv3x3_fwd_bnin / unetdc_conv3x3_wgrad_bnin (bf16): fed from the RAW output of the stage in front, they apply its
+    BatchNorm + ReLU per staged tile in LDS.  Bit-identical to the two-pass form (unetdc_bn_relu_apply, then the plain
+    kernels) -- output, statistics rows and weight gradient -- incl. image borders (zero padding of the ACTIVATION, not of
+    the raw tensor), several items per workgroup, d = 2, two K chunks, strided views."""
+    n, h, w, cin, cout, d = case
+    dtype = "bf16"
+    lib = _lib.load()
+    assert lib.unetdc_conv3x3_bnin_supported(n, h, w, cin, cout, d, G.DT[dtype]) == 1
+    assert lib.unetdc_conv3x3_bnin_supported(n, h, w, cin, 128, d, G.DT[dtype]) == 0       # 128-channel n-blocks: not built
+    g = gen(41)
+    yraw = G.quant(torch.randn(n, cin, h, w, generator=g) * 1.5, dtype)
+    sc, sh = (torch.rand(cin, generator=g) + 0.5).cuda(), (torch.randn(cin, generator=g) * 0.4 + 0.3).cuda()   # relu(shift) != 0
+    wt = G.quant(torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5), dtype)
+    b = torch.randn(cout, generator=g).cuda()
+    dy = G.quant(torch.randn(n, cout, h, w, generator=g), dtype)
+    wf, _ = G.pack_conv(wt, dtype)
+    yv = G.to_nhwc(yraw, dtype, ld=cin + 64, off=64)
+    av = G.empty_nhwc(n * h * w, cin, dtype)
+    call("unetdc_bn_relu_apply", yv.data_ptr(), yv.stride(0), sc.data_ptr(), sh.data_ptr(), av.data_ptr(), av.stride(0), None, 0,
+         n, h, w, cin, G.DT[dtype], G.stream())
+    # forward: two passes vs normalise-on-load
+    o_ref = G.empty_nhwc(n * h * w, cout, dtype)
+    st_ref, rows = G.conv3x3_fwd(av, wf, b, n, h, w, cin, cout, d, dtype, o_ref, stats=True)
+    live_ref = lib.unetdc_last_stats_rows()
+    o = G.empty_nhwc(n * h * w, cout, dtype)
+    st = torch.full_like(st_ref, float("nan"))
+    call("unetdc_conv3x3_fwd_bnin", yv.data_ptr(), yv.stride(0), sc.data_ptr(), sh.data_ptr(), wf.data_ptr(), b.data_ptr(),
+         o.data_ptr(), o.stride(0), st.data_ptr(), n, h, w, cin, cout, d, G.DT[dtype], G.stream())
+    assert lib.unetdc_last_kernel().decode().endswith("bnin")
+    assert lib.unetdc_last_stats_rows() == live_ref
+    assert torch.equal(o, o_ref)
+    assert torch.equal(st[: rows * 2 * cout], st_ref[: rows * 2 * cout])
+    # weight gradient
+    dyv = G.to_nhwc(dy, dtype)
+    dw_ref = G.conv3x3_wgrad(av, dyv, n, h, w, cin, cout, d, dtype)
+    nbytes = lib.unetdc_conv3x3_wgrad_workspace(n, h, w, cin, cout, G.DT[dtype])
+    ws = G.workspace(nbytes)
+    dw = torch.full((cout, cin, 3, 3), float("nan"), device="cuda")
+    call("unetdc_conv3x3_wgrad_bnin", yv.data_ptr(), yv.stride(0), sc.data_ptr(), sh.data_ptr(), dyv.data_ptr(), dyv.stride(0),
+         dw.data_ptr(), ws.data_ptr(), nbytes, n, h, w, cin, cout, d, G.DT[dtype], G.stream())
+    assert lib.unetdc_last_kernel().decode().endswith("bnin")
+    assert torch.equal(dw, dw_ref)
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("cin", [1, 3])
 @pytest.mark.parametrize("shape", [(2, 24, 40, 1), (1, 64, 64, 2), (3, 10, 10, 1), (1, 8, 8, 16)])

@@ -89,6 +89,48 @@ int unetdc_conv3x3_fwd(const void* x, int ldx, const void* w_fwd, const float* b
   return rc;
 }
 
+// forward conv fed from the RAW output of the stage in front of it: that stage's BatchNorm + ReLU is applied per staged patch
+int unetdc_conv3x3_bnin_supported(int n, int h, int w, int cin, int cout, int dilation, int dtype) {
+  if (n <= 0 || h <= 0 || w <= 0 || dilation < 1) return 0;
+  IgemmParams p{};
+  p.M = n * h * w; p.Ho = h; p.Wo = w; p.Hi = h; p.Wi = w; p.Cin = cin; p.Cout = cout; p.ldx = cin; p.ldo = cout;
+  p.ntaps = 9; p.stride = 1; p.mode = MODE_STATS;
+  taps3x3(dilation, p.offy, p.offx);
+  return (igemm_lattice_bnin_supported(p, dtype) && wgrad_bnin_supported(n, h, w, cout, cin, cout, cin, dilation, dtype)) ? 1 : 0;
+}
+
+int unetdc_conv3x3_fwd_bnin(const void* x_raw, int ldx, const float* in_scale, const float* in_shift, const void* w_fwd,
+                            const float* bias, void* y, int ldy, float* stats_part, int n, int h, int w, int cin, int cout,
+                            int dilation, int dtype, unetdc_stream_t s) {
+  GEOM_CHECK(n, h, w);
+  UNETDC_REQUIRE(dilation >= 1 && ldx >= cin && ldy >= cout, "conv3x3_fwd_bnin: bad dilation/ld");
+  UNETDC_REQUIRE(in_scale && in_shift && stats_part, "conv3x3_fwd_bnin: null pointer");
+  IgemmParams p{};
+  p.x = x_raw; p.w = w_fwd; p.out = y; p.bias = bias; p.stats = stats_part; p.in_scale = in_scale; p.in_shift = in_shift;
+  p.M = n * h * w; p.Ho = h; p.Wo = w; p.Hi = h; p.Wi = w; p.Cin = cin; p.Cout = cout; p.ldx = ldx; p.ldo = ldy;
+  p.ntaps = 9; p.stride = 1; p.mode = MODE_STATS;
+  taps3x3(dilation, p.offy, p.offx);
+  if (!igemm_lattice_bnin_supported(p, dtype)) {
+    set_error("conv3x3_fwd_bnin: shape not supported by the input-normalising kernel (ask unetdc_conv3x3_bnin_supported)");
+    return UNETDC_EUNSUPPORTED;
+  }
+  const int rc = launch_igemm(p, dtype, (hipStream_t)s);
+  if (rc == UNETDC_OK) g_stats_rows = p.mblocks;
+  return rc;
+}
+
+int unetdc_conv3x3_wgrad_bnin(const void* x_raw, int ldx, const float* in_scale, const float* in_shift, const void* dy,
+                              int lddy, float* dw, void* workspace, int64_t workspace_bytes, int n, int h, int w, int cin,
+                              int cout, int dilation, int dtype, unetdc_stream_t s) {
+  GEOM_CHECK(n, h, w);
+  UNETDC_REQUIRE(dilation >= 1 && in_scale && in_shift, "conv3x3_wgrad_bnin: bad arguments");
+  WgradParams p{};
+  p.a = dy; p.b = x_raw; p.N = n; p.H = h; p.W = w; p.Hb = h; p.Wb = w; p.CI = cout; p.CJ = cin;
+  p.lda = lddy; p.ldb = ldx; p.ntaps = 9; p.stride = 1; p.in_scale = in_scale; p.in_shift = in_shift;
+  taps3x3(dilation, p.offy, p.offx);
+  return launch_wgrad(p, dw, workspace, (long)workspace_bytes, dtype, (hipStream_t)s);
+}
+
 int unetdc_conv3x3_dgrad(const void* dy, int lddy, const void* w_dgrad, void* dx, int lddx, int n, int h, int w,
                          int cin, int cout, int dilation, int dtype, unetdc_stream_t s) {
   GEOM_CHECK(n, h, w);

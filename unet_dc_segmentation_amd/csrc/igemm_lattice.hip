@@ -65,9 +65,16 @@ template <int PJ, int SPT> __device__ constexpr int lat_nsl(int t) {
 }
 #endif
 
-template <int WM, int WN, int MT, int NPB, int MODE>
+// INORM (the 4-wave single-buffer form): the input is the RAW conv output of the stage in front; that stage's BatchNorm + ReLU
+// is applied ONCE per staged patch, in LDS, between the barrier behind which the patch has landed and the first tap -- the
+// stand-alone normalisation pass of that stage and its activation tensor disappear (models/model_2.py:45-46 fused into :48).
+// A thread owns one logical 16-byte chunk (8 channels: its 16 constants live in registers) of every 32nd patch pixel; padding
+// pixels (outside the sub-lattice) were zero-filled by the DMA and stay zero, which is what zero padding of the ACTIVATION means.
+// The result is rounded through bf16 like a stored activation: outputs are bit-identical to the two-pass form.
+template <int WM, int WN, int MT, int NPB, int MODE, bool INORM = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const IgemmParams p, const LatticeParams q) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(!INORM || (NPB == 1 && WM * WN == 4), "input normalisation: the 4-wave single-buffer form");
   constexpr int NW = WM * WN, BN = WN * 64;
   constexpr int BI = BN / 8 / NW;                 // weight DMA instructions per wave per tap
   constexpr int PJ = (LPI + NW - 1) / NW;         // patch DMA instructions per wave per chunk (uniform: padded)
@@ -192,6 +199,30 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
 #pragma unroll
     for (int j = 0; j < BI; ++j)
       lds_dma16(wr, lds_base + OFF_W + stage * WST + (wave + NW * j) * 1024, valid ? bbase[j] : LOOB, soff);
+  };
+
+  // INORM: normalise the patch of (item, K chunk kc) in place
+  auto normalise_patch = [&](const Item& it, int kc) {
+    const int lc = tid & 7;                       // logical chunk: channels kc * 64 + 8 lc .. + 7
+    float nsc[8], nsh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { nsc[e] = p.in_scale[kc * 64 + lc * 8 + e]; nsh[e] = p.in_shift[kc * 64 + lc * 8 + e]; }
+#pragma unroll
+    for (int i = 0; i < (LPP + 31) / 32; ++i) {
+      const int pr = (tid >> 3) + 32 * i;
+      const int ppy = (pr * 1928) >> 16, ppx = pr - ppy * LPW;       // pr / 34
+      const int ly = it.ly0 + ppy - 1, lx = it.lx0 + ppx - 1;
+      if (pr < LPP && (unsigned)ly < (unsigned)q.Hs && (unsigned)lx < (unsigned)q.Ws) {
+        unsigned char* a = smem + pr * 128 + ((lc ^ ((ppx >> 1) & 7)) << 4);
+        float v[8];
+        Chunk<bf16_t>::unpack(ld16(a), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], nsc[e], nsh[e]), 0.f);
+        st16(a, Chunk<bf16_t>::pack(v));
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    raw_barrier();
   };
 
   f32x4 acc[MT][4];
@@ -375,6 +406,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
           else wait_vmcnt<BI>();
         }
         if (!(q.dbg & 1)) raw_barrier();
+        if (INORM && t == 0) normalise_patch(cur, kc);       // the patch of this chunk has landed (every wave's pieces)
         // ---- prefetch: weights two steps ahead, patch slices of the next chunk -----------------------------------------
         if (q.dbg & 8) {
         } else if (t < 7) issue_w((t + 2) % 3, t + 2, kc, cur.nblk, true);
@@ -776,19 +808,24 @@ bool igemm_lattice_supported(const IgemmParams& p, int dtype) {
   return xbytes < (1L << 31) && wbytes < (1L << 31) && obytes < (1L << 32) && ybytes < (1L << 32);
 }
 
+// input normalisation on load: the 64-channel-output statistics forward of the 4-wave form
+bool igemm_lattice_bnin_supported(const IgemmParams& p, int dtype) {
+  return igemm_lattice_supported(p, dtype) && p.mode == MODE_STATS && p.Cout % 128 != 0;
+}
+
 static long lattice_grid(long items, int wgs_per_cu) {
   const long g = 256L * wgs_per_cu;
   return g > items ? items : g;
 }
 
-template <int WM, int WN, int MT, int NPB, int MODE>
+template <int WM, int WN, int MT, int NPB, int MODE, bool INORM = false>
 static int launch_lattice_cfg(IgemmParams& p, const LatticeParams& q, int wgs_per_cu, hipStream_t stream) {
   constexpr int NW = WM * WN, BN = WN * 64;
   constexpr int PJ = (LPI + NW - 1) / NW;
   constexpr int LDS = NPB * PJ * NW * 1024 + 3 * BN * 128 + NW * 128 * 4;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_lattice_kernel<WM, WN, MT, NPB, MODE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_lattice_kernel<WM, WN, MT, NPB, MODE, INORM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       set_error("hipFuncSetAttribute(igemm_lattice_kernel) failed: %s", hipGetErrorString(e));
@@ -802,9 +839,9 @@ static int launch_lattice_cfg(IgemmParams& p, const LatticeParams& q, int wgs_pe
     set_error("igemm_lattice: grid %ld / nblocks %d / stat_rows %d inconsistent", grid, q.nblocks, q.stat_rows);
     return UNETDC_ELAUNCH;
   }
-  hipLaunchKernelGGL((igemm_lattice_kernel<WM, WN, MT, NPB, MODE>), dim3((unsigned)grid), dim3(NW * 64), LDS, stream, p, q);
+  hipLaunchKernelGGL((igemm_lattice_kernel<WM, WN, MT, NPB, MODE, INORM>), dim3((unsigned)grid), dim3(NW * 64), LDS, stream, p, q);
   char nm[96];
-  snprintf(nm, sizeof(nm), "igemm_lattice_kernel<%d, %d, %d, %d, %d>", WM, WN, MT, NPB, MODE);
+  snprintf(nm, sizeof(nm), "igemm_lattice_kernel<%d, %d, %d, %d, %d>%s", WM, WN, MT, NPB, MODE, INORM ? " bnin" : "");
   note_kernel(nm);
   return check_launch("igemm_lattice_kernel");
 }
@@ -883,6 +920,7 @@ int launch_igemm_lattice(IgemmParams& p, hipStream_t stream) {
     return launch_lattice_wide_cfg<MODE_AFFINE_RELU>(p, q, stream);
   }
   if (wide) return launch_lattice_mode<4, 2, 4, 2>(p, q, 1, stream);
+  if (p.in_scale) return launch_lattice_cfg<4, 1, 4, 1, MODE_STATS, true>(p, q, 2, stream);      // igemm_lattice_bnin_supported
   return launch_lattice_mode<4, 1, 4, 1>(p, q, 2, stream);
 }
 

@@ -26,6 +26,10 @@ struct IgemmParams {
   int mblocks, nblocks;
   int wo_shift, howo_shift;  // log2(Wo), log2(Ho*Wo) when both are powers of two, else -1 (set by launch_igemm)
   int quad_bpr, quad_bpi;    // > 0: the M index walks 16 x 16 pixel blocks (blocks per image row / per image), see igemm_dma16.hip
+  // input normalisation ("bnin"): x is the RAW conv output of the producing stage; its BatchNorm + ReLU, relu(in_scale * x +
+  // in_shift) rounded through the storage type, is applied to every staged patch in LDS (igemm_lattice.hip, INORM)
+  const float* in_scale;
+  const float* in_shift;
   int offy[9];
   int offx[9];
 };
@@ -33,6 +37,7 @@ int launch_igemm(IgemmParams& p, int dtype, hipStream_t stream);
 int igemm_mblocks(long M, int Cout);
 bool igemm_lattice_supported(const IgemmParams& p, int dtype);      // igemm_lattice.hip: persistent lattice-halo conv (bf16)
 int launch_igemm_lattice(IgemmParams& p, hipStream_t stream);
+bool igemm_lattice_bnin_supported(const IgemmParams& p, int dtype);  // x = raw conv output, BatchNorm + ReLU applied per staged patch
 bool igemm_dma16_supported(const IgemmParams& p, int dtype);
 int launch_igemm_dma16(IgemmParams& p, int cfg, hipStream_t stream);
 
@@ -47,8 +52,11 @@ struct WgradParams {
   int adv_y, adv_x; // pixel step decomposed: step = adv_y*W + adv_x
   int offy[9];
   int offx[9];
+  const float* in_scale;   // "bnin": b (the conv input) is the RAW output of the producing stage, normalised on load
+  const float* in_shift;
 };
 int launch_wgrad(WgradParams& p, float* out, void* workspace, long workspace_bytes, int dtype, hipStream_t stream);
+bool wgrad_bnin_supported(int N, int H, int W, int CI, int CJ, int lda, int ldb, int d, int dtype);
 long wgrad_workspace_bytes(long P, int CI, int CJ, int ntaps, int dtype);
 long wgrad_fused_workspace_bytes(int N, int H, int W, int CI, int CJ, int dtype);
 long wgrad_rect_workspace_bytes(int N, int H, int W, int CI, int CJ, int d);

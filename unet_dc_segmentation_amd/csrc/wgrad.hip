@@ -235,7 +235,8 @@ bool wgrad_fused_supported(int N, int H, int W, int CI, int CJ, int lda, int ldb
                            int dtype);
 long wgrad_fused_workspace_bytes(int N, int H, int W, int CI, int CJ, int dtype);
 int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* part, int N, int H, int W, int CI,
-                       int CJ, int d, int dtype, int* units_out, hipStream_t stream);
+                       int CJ, int d, int dtype, int* units_out, hipStream_t stream, const float* in_scale = nullptr,
+                       const float* in_shift = nullptr);
 
 // valid-rectangle kernel for strongly dilated layers, wgrad_rect.hip
 bool wgrad_rect_supported(int N, int H, int W, int CI, int CJ, int lda, int ldb, int d, int ntaps, int stride, int dtype);
@@ -334,11 +335,16 @@ int launch_wgrad(WgradParams& p, float* out, void* workspace, long workspace_byt
   const long P = (long)p.N * p.H * p.W;
   UNETDC_REQUIRE(P > 0 && P < (1L << 31) - 4096, "wgrad: pixel count out of range");
   p.P = (int)P;
-  if (wgrad_choice() == 0 && p.Hb == p.H && p.Wb == p.W &&
+  if (p.in_scale) {                               // input normalisation on load: the tap-split ring kernel only (caller asked wgrad_bnin_supported)
+    UNETDC_REQUIRE(p.in_shift && p.Hb == p.H && p.Wb == p.W && p.ntaps == 9 && p.stride == 1 &&
+                       wgrad_bnin_supported(p.N, p.H, p.W, p.CI, p.CJ, p.lda, p.ldb, p.offy[8], dtype),
+                   "wgrad (bnin): shape not supported by the input-normalising kernel");
+  }
+  if (!p.in_scale && wgrad_choice() == 0 && p.Hb == p.H && p.Wb == p.W &&
       wgrad_rect_supported(p.N, p.H, p.W, p.CI, p.CJ, p.lda, p.ldb, p.offy[8], p.ntaps, p.stride, dtype))
     return launch_wgrad_rect(p.a, p.lda, p.b, p.ldb, out, workspace, workspace_bytes, p.N, p.H, p.W, p.CI, p.CJ, p.offy[8],
                              stream);
-  if (wgrad_choice() == 0 && p.Hb == p.H && p.Wb == p.W &&
+  if ((p.in_scale || wgrad_choice() == 0) && p.Hb == p.H && p.Wb == p.W &&
       wgrad_fused_supported(p.N, p.H, p.W, p.CI, p.CJ, p.lda, p.ldb, p.offy[8], p.ntaps, p.stride, dtype)) {
     const long need_f = wgrad_fused_workspace_bytes(p.N, p.H, p.W, p.CI, p.CJ, dtype);
     if (need_f > workspace_bytes) {
@@ -347,7 +353,7 @@ int launch_wgrad(WgradParams& p, float* out, void* workspace, long workspace_byt
     }
     int units = 0;
     int rc = launch_wgrad_fused(p.a, p.lda, p.b, p.ldb, reinterpret_cast<float*>(workspace), p.N, p.H, p.W, p.CI,
-                                p.CJ, p.offy[8], dtype, &units, stream);
+                                p.CJ, p.offy[8], dtype, &units, stream, p.in_scale, p.in_shift);
     if (rc != UNETDC_OK) return rc;
     const long n = (long)p.CI * p.CJ * p.ntaps;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, stream,

@@ -32,6 +32,10 @@ struct WgradFusedParams {
   int N, H, W, CI, CJ, lddy, ldx, d;
   int ysplit, rows_per_unit, itiles, jtiles;
   int imgs_per_unit;   // tap-split ring kernel with ysplit == 1: a workgroup walks this many images of its segment in turn
+  // input normalisation ("bnin", tap-split ring kernel): x is the RAW conv output of the producing stage; every X row is
+  // normalised in LDS, relu(in_scale * x + in_shift) rounded through bf16, once, when it has landed
+  const float* in_scale;
+  const float* in_shift;
 };
 
 template <typename T> struct FusedCfg;
@@ -600,7 +604,7 @@ template <bool M16> __device__ __forceinline__ int split_src_chunk(int row, int 
   return M16 ? Frag16::src_chunk(row, pc) : Frag<bf16_t, 1>::src_chunk(row, pc);
 }
 
-template <int PF, int TG, bool M16>
+template <int PF, int TG, bool M16, bool INORM>
 __device__ __forceinline__ void ring_split_body(const WgradFusedParams& p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using T = bf16_t;
@@ -687,6 +691,35 @@ __device__ __forceinline__ void ring_split_body(const WgradFusedParams& p) {
   SplitAcc<M16> acc;
   split_zero(acc);
   const Split16Offs offs = split_offsets<M16>(lane, qj, d);
+  // INORM: the 64 (scale, shift) pairs of this workgroup's input-channel tile live in LDS behind the ring (no vector-memory
+  // operation may join the hand-counted DMA queue inside the row loop); a thread owns logical chunk tid & 7 of every 32nd
+  // pixel of a row.  Rows / pixels outside the image were zero-filled by the DMA and stay zero (zero padding of the
+  // ACTIVATION); the result is rounded through bf16 like a stored activation: bit-identical to the two-pass form.
+  float* const ncst = reinterpret_cast<float*>(xring + R * XB);              // [2][64]
+  if (INORM) {
+    if (tid < 128) ncst[tid] = (tid < 64 ? p.in_scale : p.in_shift)[j0 + (tid & 63)];
+    __syncthreads();
+  }
+  auto normalise_row = [&](int slot, int yy) {
+    if ((unsigned)yy >= (unsigned)p.H) return;                               // a zero row (wave-uniform condition)
+    const int lc = tid & 7;
+    float nsc[8], nsh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { nsc[e] = ncst[lc * 8 + e]; nsh[e] = ncst[64 + lc * 8 + e]; }
+#pragma unroll
+    for (int i = 0; i < (XR + 31) / 32; ++i) {
+      const int px = (tid >> 3) + 32 * i;
+      const int gx = x0 - d + px;
+      if (px < XR && (unsigned)gx < (unsigned)p.W) {
+        unsigned char* a = xring + slot * XB + px * RB + (split_src_chunk<M16>(px, lc) << 4);
+        float v[8];
+        Chunk<bf16_t>::unpack(ld16(a), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], nsc[e], nsh[e]), 0.f);
+        st16(a, Chunk<bf16_t>::pack(v));
+      }
+    }
+  };
 
   for (int img = 0; img < ipu && n0 + img < p.N; ++img) {
   n = n0 + img;
@@ -711,6 +744,16 @@ __device__ __forceinline__ void ring_split_body(const WgradFusedParams& p) {
       wait_vmcnt<0>();
     }
     raw_barrier();
+    if (INORM) {
+      // the X rows that have landed with this step and were not normalised yet: at the first step of an image the 2d rows
+      // issued up front and the row of group 0, afterwards the one new row y + d (ring slot sl2)
+      if (s == 0) {
+        for (int rho = 0; rho < 2 * d; ++rho) normalise_row(rho, ybeg - d + rho);
+      }
+      normalise_row(sl2, ybeg + s + d);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      raw_barrier();
+    }
     if (s + PF < nsteps) {
       issue_dy(gslot_dy, ybeg + s + PF);
       issue_x(gslot_x, ybeg + s + PF + d);
@@ -731,12 +774,12 @@ __device__ __forceinline__ void ring_split_body(const WgradFusedParams& p) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int PF, bool M16>
+template <int PF, bool M16, bool INORM = false>
 __global__ __launch_bounds__(256, 2) void wgrad_ring_split_kernel(const WgradFusedParams p) {
   // the tap group is wave-uniform: two specialisations of the whole body, so the 160 accumulator registers of a wave
   // never meet in a phi (a per-step branch made the allocator spill ~590 registers)
-  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7) == 0) ring_split_body<PF, 0, M16>(p);
-  else ring_split_body<PF, 1, M16>(p);
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7) == 0) ring_split_body<PF, 0, M16, INORM>(p);
+  else ring_split_body<PF, 1, M16, INORM>(p);
 }
 
 template <int TG, bool M16>
@@ -895,11 +938,20 @@ long wgrad_fused_workspace_bytes(int N, int H, int W, int CI, int CJ, int dtype)
 }
 
 // Fills the slabs; the caller reduces `units` slabs with wgrad_reduce_kernel.
+bool wgrad_bnin_supported(int N, int H, int W, int CI, int CJ, int lda, int ldb, int d, int dtype) {
+  static int m16s = -1, splits = -1;
+  if (m16s < 0) { const char* e = getenv("UNETDC_WGRAD_M16"); m16s = (e && e[0] == '0') ? 0 : 1; }
+  if (splits < 0) { const char* e = getenv("UNETDC_WGRAD_SPLIT"); splits = (e && e[0] == '0') ? 0 : 1; }
+  return dtype == UNETDC_BF16 && m16s && splits && wgrad_fused_supported(N, H, W, CI, CJ, lda, ldb, d, 9, 1, dtype) &&
+         ring_pf(d, dtype) > 0;
+}
+
 int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* part, int N, int H, int W, int CI,
-                       int CJ, int d, int dtype, int* units_out, hipStream_t stream) {
+                       int CJ, int d, int dtype, int* units_out, hipStream_t stream, const float* in_scale,
+                       const float* in_shift) {
   WgradFusedParams p{};
   p.dy = dy; p.x = x; p.part = part; p.N = N; p.H = H; p.W = W; p.CI = CI; p.CJ = CJ; p.lddy = lddy; p.ldx = ldx;
-  p.d = d;
+  p.d = d; p.in_scale = in_scale; p.in_shift = in_shift;
   fused_plan(N, H, W, CI, CJ, dtype, p.ysplit, p.rows_per_unit);
   p.itiles = CI / 64;
   p.jtiles = CJ / 64;
@@ -911,8 +963,12 @@ int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* 
   if (split < 0) { const char* e = getenv("UNETDC_WGRAD_SPLIT"); split = (e && e[0] == '0') ? 0 : 1; }
   static int m16 = -1;                                   // UNETDC_WGRAD_M16=0: the 32x32x16 form of the tap-split kernels (A/B)
   if (m16 < 0) { const char* e = getenv("UNETDC_WGRAD_M16"); m16 = (e && e[0] == '0') ? 0 : 1; }
+  if (in_scale && !(pf && dtype == UNETDC_BF16 && split && m16)) {
+    set_error("wgrad (bnin): the input-normalising form exists for the 16x16x32 tap-split ring kernel only");
+    return UNETDC_EUNSUPPORTED;
+  }
   if (pf && dtype == UNETDC_BF16 && split) {
-    const int lds = ring_lds(d, dtype, pf);
+    const int lds = ring_lds(d, dtype, pf) + (in_scale ? 512 : 0);
     long nwg = (long)units * p.itiles * p.jtiles;
     if (p.ysplit == 1 && nwg > 512 && N > 1) {           // more than two workgroups per CU: walk several images per workgroup
       int ipu = (int)((nwg + 511) / 512);
@@ -933,6 +989,23 @@ int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* 
         return UNETDC_ELAUNCH;
       }
       split_attr[pf] = true;
+    }
+    if (in_scale) {
+      static bool nattr[3] = {false, false, false};
+      const void* nfn = pf == 2 ? reinterpret_cast<const void*>(&wgrad_ring_split_kernel<2, true, true>)
+                                : reinterpret_cast<const void*>(&wgrad_ring_split_kernel<1, true, true>);
+      if (!nattr[pf]) {
+        hipError_t e = hipFuncSetAttribute(nfn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) {
+          set_error("hipFuncSetAttribute(wgrad_ring_split_kernel bnin) failed: %s", hipGetErrorString(e));
+          return UNETDC_ELAUNCH;
+        }
+        nattr[pf] = true;
+      }
+      if (pf == 2) hipLaunchKernelGGL((wgrad_ring_split_kernel<2, true, true>), dim3((unsigned)nwg), dim3(256), lds, stream, p);
+      else hipLaunchKernelGGL((wgrad_ring_split_kernel<1, true, true>), dim3((unsigned)nwg), dim3(256), lds, stream, p);
+      note_kernel(pf == 2 ? "wgrad_ring_split_kernel<2, 16x16x32> bnin" : "wgrad_ring_split_kernel<1, 16x16x32> bnin");
+      return check_launch("wgrad_ring_split_kernel(bnin)");
     }
     if (pf == 2 && m16) hipLaunchKernelGGL((wgrad_ring_split_kernel<2, true>), dim3((unsigned)nwg), dim3(256), lds, stream, p);
     else if (pf == 2) hipLaunchKernelGGL((wgrad_ring_split_kernel<2, false>), dim3((unsigned)nwg), dim3(256), lds, stream, p);

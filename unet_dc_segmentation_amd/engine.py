@@ -43,6 +43,11 @@ FUSE_POOL_SKIP = os.environ.get("UNETDC_FUSE_POOL_SKIP", "0") == "1" and FUSE_CO
 # recomputes the activation the same way): dec1.3's normalisation pass and its 268 MB activation tensor disappear from the
 # training step.  UNETDC_FUSE_HEAD_BN=0: stand-alone pass (A/B switch)
 FUSE_HEAD_BN = os.environ.get("UNETDC_FUSE_HEAD_BN", "1") != "0" and FUSE_BN_BWD
+# Second stage of a block fed from the first stage's RAW conv output ("bnin"): the consumer convolution and its weight gradient
+# apply the first stage's BatchNorm + ReLU per staged tile in LDS (unetdc_conv3x3_fwd_bnin / unetdc_conv3x3_wgrad_bnin), so
+# that stage's normalisation pass and activation tensor disappear.  Used where the library has the kernels (bf16, 64-channel
+# blocks: enc1 and dec1, the two largest normalisation passes of the step).  UNETDC_FUSE_BNIN=0: stand-alone passes (A/B)
+FUSE_BNIN = os.environ.get("UNETDC_FUSE_BNIN", "1") != "0"
 # Opt-in (UNETDC_SIDE_WGRAD=1): run the weight-gradient kernels, which hang off the backward critical chain, on a side
 # HIP stream.  Measured on MI355X in round 3 (same-box A/B, profiles/r03_side_stream_ab.txt): +1.3 ... +2.2 % with the 32x32x16
 # weight gradient, within noise since it moved to 16x16x32 MFMAs (11.41 vs 11.36 / 11.49 ms per step).  What overlapped was
@@ -171,6 +176,7 @@ class _Stage:
         self.stats = torch.empty((rows + 64) * 2 * cout, **f32)
         self.scale, self.shift = torch.empty(cout, **f32), torch.empty(cout, **f32)
         self.mean, self.rstd = torch.empty(cout, **f32), torch.empty(cout, **f32)
+        self.bnin = None      # (scale, shift) of the stage whose RAW output is this stage's input (normalised on load)
         self.x_in = None      # input view of the last forward (for wgrad)
         self.a_out = None     # activated output view
         # BatchNorm-backward partial sums produced by the dgrad kernel that writes this stage's
@@ -263,6 +269,13 @@ class UNetEngine:
             self.a3[f"dec{lvl}"] = torch.empty(self.npix[lvl - 1], c, device=dev, dtype=dt)
         # transposed convs: module, sizes, packed weights (shared), input view of the last forward
         self.up = {lvl: dict(self.weights.up[lvl]) for lvl in (4, 3, 2, 1)}
+        # blocks whose second stage normalises the first stage's raw output on load
+        self.bnin_blocks = set()
+        if FUSE_BNIN:
+            for (name, idx), st in self.stages.items():
+                h, w = st.hw
+                if idx == 3 and lib.unetdc_conv3x3_bnin_supported(N, h, w, st.cin, st.cout, st.dil, self.dt):
+                    self.bnin_blocks.add(name)
         # gradient-side buffers (allocated lazily on the first backward)
         self.grad_bufs = None
         # parameter order == model.parameters() order; flat gradient offsets
@@ -317,7 +330,7 @@ class UNetEngine:
             return _UNetFunction.apply(x, self, not model.training, *self.params)
         return self.forward(x, train=False)
 
-    def _stage_fwd(self, st, xin, dst, train, pooled=None, apply=True, frozen=False):
+    def _stage_fwd(self, st, xin, dst, train, pooled=None, apply=True, frozen=False, bnin=None):
         """conv -> BN -> ReLU.  xin: [npix, cin] view (or the NCHW image for the first stage);
         dst: [npix, cout] view receiving the activation; pooled: optional [npix/4, cout] view;
         apply=False (train mode only): stop after the batch statistics -- the consumer normalises on load."""
@@ -326,9 +339,15 @@ class UNetEngine:
         h, w = st.hw
         conv, bn = st.conv, st.bn
         st.x_in, st.a_out = xin, dst
+        st.bnin = bnin if train else None
         if train:
             y = st.y
-            if st.first:
+            if bnin is not None:                   # xin = the RAW output of the stage in front, normalised per staged patch
+                call("unetdc_conv3x3_fwd_bnin", xin.data_ptr(), xin.stride(0), bnin[0].data_ptr(), bnin[1].data_ptr(),
+                     st.w_fwd.data_ptr(), conv.bias.data_ptr(), y.data_ptr(), y.stride(0), st.stats.data_ptr(), N, h, w,
+                     st.cin, st.cout, st.dil, self.dt, s)
+                st.stat_rows = _lib.load().unetdc_last_stats_rows()
+            elif st.first:
                 call("unetdc_conv3x3_first_fwd", xin.data_ptr(), conv.weight.data_ptr(), conv.bias.data_ptr(),
                      None, None, y.data_ptr(), y.stride(0), st.stats.data_ptr(), N, h, w, st.cin, st.cout,
                      st.dil, self.dt, s)
@@ -383,9 +402,12 @@ class UNetEngine:
         hin = x
         for l, name in enumerate(ENCODER):
             c = widths[l]
-            self._stage_fwd(self.stages[(name, 0)], hin, self.a0[name], train, frozen=frozen)
+            s0 = self.stages[(name, 0)]
+            fuse = train and name in self.bnin_blocks      # stage 3 reads stage 0's raw output and normalises it on load
+            self._stage_fwd(s0, hin, self.a0[name], train, frozen=frozen, apply=not fuse)
             skip = self.cat[l + 1][:, c:]
-            self._stage_fwd(self.stages[(name, 3)], self.a0[name], skip, train, pooled=self.pool[l + 1], frozen=frozen)
+            self._stage_fwd(self.stages[(name, 3)], s0.y if fuse else self.a0[name], skip, train, pooled=self.pool[l + 1],
+                            frozen=frozen, bnin=(s0.scale, s0.shift) if fuse else None)
             hin = self.pool[l + 1]
         self._stage_fwd(self.stages[("bottleneck", 0)], hin, self.a0["bottleneck"], train, frozen=frozen)
         self._stage_fwd(self.stages[("bottleneck", 3)], self.a0["bottleneck"], self.a3["bottleneck"], train, frozen=frozen)
@@ -400,8 +422,11 @@ class UNetEngine:
                  u["mod"].bias.data_ptr(), upv.data_ptr(), upv.stride(0), N, h, w, u["cin"], c, self.dt, s)
             name = f"dec{lvl}"
             head_norm = train and FUSE_HEAD_BN and lvl == 1          # dec1.3: normalised by the head while loading
-            self._stage_fwd(self.stages[(name, 0)], self.cat[lvl], self.a0[name], train, frozen=frozen)
-            self._stage_fwd(self.stages[(name, 3)], self.a0[name], self.a3[name], train, apply=not head_norm, frozen=frozen)
+            s0 = self.stages[(name, 0)]
+            fuse = train and name in self.bnin_blocks
+            self._stage_fwd(s0, self.cat[lvl], self.a0[name], train, frozen=frozen, apply=not fuse)
+            self._stage_fwd(self.stages[(name, 3)], s0.y if fuse else self.a0[name], self.a3[name], train,
+                            apply=not head_norm, frozen=frozen, bnin=(s0.scale, s0.shift) if fuse else None)
             hin = self.a3[name]
         probs = torch.empty(N, self.oc, self.H, self.W, device=self.device, dtype=torch.float32)
         oc = self.model.out_conv
@@ -515,6 +540,10 @@ class UNetEngine:
                 if st.first:
                     call("unetdc_conv3x3_first_wgrad", xin.data_ptr(), dy.data_ptr(), dy.stride(0), dw.data_ptr(), ws2, wsb,
                          N, h, w, st.cin, st.cout, st.dil, self.dt, s2)
+                elif st.bnin is not None:
+                    call("unetdc_conv3x3_wgrad_bnin", xin.data_ptr(), xin.stride(0), st.bnin[0].data_ptr(),
+                         st.bnin[1].data_ptr(), dy.data_ptr(), dy.stride(0), dw.data_ptr(), ws2, wsb, N, h, w, st.cin,
+                         st.cout, st.dil, self.dt, s2)
                 else:
                     call("unetdc_conv3x3_wgrad", xin.data_ptr(), xin.stride(0), dy.data_ptr(), dy.stride(0), dw.data_ptr(),
                          ws2, wsb, N, h, w, st.cin, st.cout, st.dil, self.dt, s2)
