@@ -61,7 +61,7 @@ def synthetic_batch(seed, n, h, w, cin=1, discs=200):
 def igemm_flops(name, a, es=2):
     """(nominal dense FLOPs incl. padded taps, algorithmic bytes = input + weights + output read/written
     once) of one implicit-GEMM launch, from its C-ABI arguments."""
-    if name == "unetdc_conv3x3_fwd":
+    if name in ("unetdc_conv3x3_fwd", "unetdc_conv3x3_fwd_bnin"):      # (bnin: input = the raw output of the stage in front)
         n, h, w, cin, cout = a[9:14]
         return 2.0 * n * h * w * cout * cin * 9, (n * h * w * (cin + cout) + 9 * cin * cout) * es
     if name == "unetdc_conv3x3_dgrad":
@@ -139,11 +139,15 @@ def per_layer_table(step, args):
         name = tagged.split("|")[0]
         fl, shape = 0.0, ""
         ints = [v for v in a if isinstance(v, int) and 0 < v < 100000]
-        if name in ("unetdc_conv3x3_fwd", "unetdc_conv3x3_dgrad", "unetdc_convT2x2_fwd", "unetdc_convT2x2_dgrad",
-                    "unetdc_conv3x3_dgrad_bnstats", "unetdc_convT2x2_dgrad_bnstats", "unetdc_conv3x3_dgrad_colsum"):
+        if name in ("unetdc_conv3x3_fwd", "unetdc_conv3x3_fwd_bnin", "unetdc_conv3x3_dgrad", "unetdc_convT2x2_fwd",
+                    "unetdc_convT2x2_dgrad", "unetdc_conv3x3_dgrad_bnstats", "unetdc_convT2x2_dgrad_bnstats",
+                    "unetdc_conv3x3_dgrad_colsum"):
             fl, _ = igemm_flops(name, a)
         elif name == "unetdc_conv3x3_wgrad":
             n, h, w, cin, cout = a[7:12]
+            fl = 2.0 * n * h * w * cin * cout * 9
+        elif name == "unetdc_conv3x3_wgrad_bnin":
+            n, h, w, cin, cout = a[9:14]
             fl = 2.0 * n * h * w * cin * cout * 9
         elif name == "unetdc_convT2x2_wgrad":
             n, h, w, cin, cout = a[7:12]
@@ -523,7 +527,7 @@ def main():
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
-    igemm_calls = ["unetdc_conv3x3_fwd", "unetdc_conv3x3_dgrad", "unetdc_convT2x2_fwd", "unetdc_convT2x2_dgrad",
+    igemm_calls = ["unetdc_conv3x3_fwd", "unetdc_conv3x3_fwd_bnin", "unetdc_conv3x3_dgrad", "unetdc_convT2x2_fwd", "unetdc_convT2x2_dgrad",
                    "unetdc_conv3x3_dgrad_bnstats", "unetdc_convT2x2_dgrad_bnstats", "unetdc_conv3x3_dgrad_colsum"]
     if args.per_layer:
         per_layer_table(step, args)

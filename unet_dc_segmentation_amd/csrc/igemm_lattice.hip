@@ -201,12 +201,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
       lds_dma16(wr, lds_base + OFF_W + stage * WST + (wave + NW * j) * 1024, valid ? bbase[j] : LOOB, soff);
   };
 
+  // INORM: the producing stage's (scale, shift) pairs sit in LDS behind the statistics scratch, [2][Cin] floats, written once:
+  // a vector-memory load inside the item loop would make the compiler drain the VM queue (the previous item's epilogue
+  // stores) in front of every patch -- that drain, not the arithmetic, made the first form of this pass cost 3.4 us per item
+  float* const ncst = reinterpret_cast<float*>(smem + OFF_RED + NW * 512);
+  if (INORM) {
+    for (int i = tid; i < 2 * p.Cin; i += NW * 64) ncst[i] = (i < p.Cin ? p.in_scale[i] : p.in_shift[i - p.Cin]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (the first barrier of the pipeline publishes it)
+  }
   // INORM: normalise the patch of (item, K chunk kc) in place
   auto normalise_patch = [&](const Item& it, int kc) {
     const int lc = tid & 7;                       // logical chunk: channels kc * 64 + 8 lc .. + 7
     float nsc[8], nsh[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { nsc[e] = p.in_scale[kc * 64 + lc * 8 + e]; nsh[e] = p.in_shift[kc * 64 + lc * 8 + e]; }
+    for (int e = 0; e < 8; ++e) { nsc[e] = ncst[kc * 64 + lc * 8 + e]; nsh[e] = ncst[p.Cin + kc * 64 + lc * 8 + e]; }
 #pragma unroll
     for (int i = 0; i < (LPP + 31) / 32; ++i) {
       const int pr = (tid >> 3) + 32 * i;
@@ -810,7 +818,7 @@ bool igemm_lattice_supported(const IgemmParams& p, int dtype) {
 
 // input normalisation on load: the 64-channel-output statistics forward of the 4-wave form
 bool igemm_lattice_bnin_supported(const IgemmParams& p, int dtype) {
-  return igemm_lattice_supported(p, dtype) && p.mode == MODE_STATS && p.Cout % 128 != 0;
+  return igemm_lattice_supported(p, dtype) && p.mode == MODE_STATS && p.Cout % 128 != 0 && p.Cin <= 256;
 }
 
 static long lattice_grid(long items, int wgs_per_cu) {
@@ -822,7 +830,7 @@ template <int WM, int WN, int MT, int NPB, int MODE, bool INORM = false>
 static int launch_lattice_cfg(IgemmParams& p, const LatticeParams& q, int wgs_per_cu, hipStream_t stream) {
   constexpr int NW = WM * WN, BN = WN * 64;
   constexpr int PJ = (LPI + NW - 1) / NW;
-  constexpr int LDS = NPB * PJ * NW * 1024 + 3 * BN * 128 + NW * 128 * 4;
+  constexpr int LDS = NPB * PJ * NW * 1024 + 3 * BN * 128 + NW * 128 * 4 + (INORM ? 2048 : 0);   // INORM: + [2][Cin <= 256] constants
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_lattice_kernel<WM, WN, MT, NPB, MODE, INORM>),
