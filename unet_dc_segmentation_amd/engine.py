@@ -12,9 +12,12 @@ Data layout in HBM
   its skip into columns ``[C, 2C)``; the concat itself moves no bytes, and in backward the two halves
   of the concat gradient are consumed in place (ConvT backward / encoder backward);
 * per conv stage the raw (pre-BatchNorm) output ``y`` is kept for backward; the activation
-  ``a = relu(scale*y + shift)`` is stored once (it is the next conv's input and the wgrad operand);
+  ``a = relu(scale*y + shift)`` is stored once (it is the next conv's input and the wgrad operand) --
+  except where the consumer normalises ``y`` on load (training): the last stage (the head reads ``y``) and
+  the first stage of the 64-channel blocks (the second stage's conv and weight gradient read ``y``, "bnin");
 * parameters stay fp32 ``nn.Parameter``s in PyTorch layout; K-contiguous packed copies in the
-  compute type are derived caches re-packed when a parameter's version counter changes;
+  compute type are derived caches (ONE set per module, shared by the engines of every input shape)
+  re-packed when a parameter's version counter changes or rewritten by the optimizer kernel;
 * gradients are written by the kernels straight into one flat fp32 buffer in ``parameters()``
   order (so data-parallel buckets are contiguous slices, see dp.py).
 """
