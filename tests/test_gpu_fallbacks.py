@@ -21,8 +21,9 @@ SWITCH_SETS = {
     # is also the fp32 path), quadrant ring and per-tap weight gradients instead of the tap-split ring and the valid-rectangle
     # kernel, per-pixel first-layer wgrad
     "round1_kernels": {"UNETDC_LATTICE": "0", "UNETDC_WGRAD_SPLIT": "0", "UNETDC_WGRAD_RECT": "0", "UNETDC_FIRST_ROWS": "0"},
-    # round-3 choices off: 32x32x16 MFMA shape in the tap-split weight gradient, row-major blocks for d % 16 == 0
-    "round3_ab": {"UNETDC_WGRAD_M16": "0", "UNETDC_QUAD": "0"},
+    # round-3 choices off: 32x32x16 MFMA shape in the tap-split weight gradient, row-major blocks for d % 16 == 0, two-stage
+    # ring with every wave in the same phase in the per-tap kernel
+    "round3_ab": {"UNETDC_WGRAD_M16": "0", "UNETDC_QUAD": "0", "UNETDC_DMA16_RING": "2", "UNETDC_DMA16_STAGGER": "0"},
 }
 
 
@@ -35,7 +36,7 @@ def test_operator_parity_under_switches(name):
     if name == "round1_kernels":
         sel = "(" + sel + " or wgrad_tap_fused) and not f32"
     if name == "round3_ab":                                # bf16-only kernel choices
-        sel = "(conv3x3_fwd_dgrad_wgrad or wgrad_tap_fused) and not f32"
+        sel = "(conv3x3_fwd_dgrad_wgrad or wgrad_tap_fused or conv_transpose) and not f32"
     cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_ops.py"), "-m", "gpu", "-x", "-q",
            "-k", sel, "-p", "no:cacheprovider"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)

@@ -56,12 +56,61 @@ int reduce_parts(const float* parts, int nparts, int L, const float** red_ptr, i
 //   parts[i][0][c] = partial sum, parts[i][1][c] = partial sum of squares
 //   scale = gamma*rstd, shift = beta - mean*scale; running stats use the UNBIASED variance.
 // ================================================================================================
-// 32 lanes cooperate on one channel (partials summed in fp64, fixed lane order -> deterministic);
-// a serial per-thread loop over the partial rows cost ~17 us per launch in load latency alone.
+// A workgroup owns FOUR consecutive channels: thread t takes partial rows t, t + 256, ... (one 16-byte load per row and
+// statistic -- at most two trips for the <= 512 rows the producers write, all loads in flight at once), fp64 from there
+// on: wave shuffle, then the four waves in fixed order through LDS -> deterministic.  (The first form, a serial per-thread
+// loop over the rows, cost ~17 us per launch in load latency alone; the second, 32 lanes per channel and 16 dependent trips,
+// 6.5-13 us.)
+constexpr int FIN_C = 4;
+
 __device__ __forceinline__ double lane32_sum(double v) {
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
   return v;
+}
+
+template <int NROW>
+__device__ __forceinline__ void fin_rows(const float* __restrict__ parts, int nparts, int cs, int col, int nch,
+                                         double (&acc)[NROW][FIN_C]) {
+  const bool vec = nch == FIN_C && ((cs | col) & 3) == 0 && (reinterpret_cast<uintptr_t>(parts) & 15) == 0;
+  for (int i = threadIdx.x; i < nparts; i += 256) {
+#pragma unroll
+    for (int w = 0; w < NROW; ++w) {
+      const float* src = parts + ((long)i * NROW + w) * cs + col;
+      float v[FIN_C] = {0.f, 0.f, 0.f, 0.f};
+      if (vec) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+        for (int e = 0; e < FIN_C; ++e) v[e] = t[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < FIN_C; ++e) if (e < nch) v[e] = src[e];
+      }
+#pragma unroll
+      for (int e = 0; e < FIN_C; ++e) acc[w][e] += (double)v[e];
+    }
+  }
+}
+
+// totals of the workgroup in red[w * FIN_C + e] (valid after the call for every thread)
+template <int NROW>
+__device__ __forceinline__ void fin_block_sum(double (&acc)[NROW][FIN_C], double* red, double* tot) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int w = 0; w < NROW; ++w)
+#pragma unroll
+    for (int e = 0; e < FIN_C; ++e) {
+      double v = acc[w][e];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) red[wave * NROW * FIN_C + w * FIN_C + e] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < NROW * FIN_C) {
+    const int k = threadIdx.x;
+    tot[k] = ((red[k] + red[NROW * FIN_C + k]) + red[2 * NROW * FIN_C + k]) + red[3 * NROW * FIN_C + k];
+  }
+  __syncthreads();
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ parts, int nparts, double count,
@@ -69,16 +118,15 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           const float* __restrict__ beta, float eps, float momentum,
                                                           float* running_mean, float* running_var, float* scale,
                                                           float* shift, float* mean_out, float* rstd_out, int C) {
-  const int c = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int i = l; i < nparts; i += 32) {
-    s += (double)parts[((long)i * 2 + 0) * C + c];
-    q += (double)parts[((long)i * 2 + 1) * C + c];
-  }
-  s = lane32_sum(s);
-  q = lane32_sum(q);
-  if (l != 0) return;
+  __shared__ double red[4 * 2 * FIN_C], tot[2 * FIN_C];
+  const int c4 = blockIdx.x * FIN_C;
+  const int nch = min(FIN_C, C - c4);
+  double acc[2][FIN_C] = {};
+  fin_rows<2>(parts, nparts, C, c4, nch, acc);
+  fin_block_sum<2>(acc, red, tot);
+  if ((int)threadIdx.x >= nch) return;
+  const int c = c4 + threadIdx.x;
+  const double s = tot[threadIdx.x], q = tot[FIN_C + threadIdx.x];
   const double mean = s / count;
   double var = q / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -289,23 +337,16 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               const float* __restrict__ rstd, float* dgamma,
                                                               float* dbeta, float* dbias, float* k1, float* k2,
                                                               float* k3, int C, int frozen) {
-  const int c = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  for (int i = l; i < nparts; i += 32) {
-    s1 += (double)parts[((long)i * 3 + 0) * cs + c0 + c];
-    s2 += (double)parts[((long)i * 3 + 1) * cs + c0 + c];
-    s3 += (double)parts[((long)i * 3 + 2) * cs + c0 + c];
-  }
-  for (int i = l; i < nparts2; i += 32) {
-    s1 += (double)parts2[((long)i * 3 + 0) * C + c];
-    s2 += (double)parts2[((long)i * 3 + 1) * C + c];
-    s3 += (double)parts2[((long)i * 3 + 2) * C + c];
-  }
-  s1 = lane32_sum(s1);
-  s2 = lane32_sum(s2);
-  s3 = lane32_sum(s3);
-  if (l != 0) return;
+  __shared__ double red[4 * 3 * FIN_C], tot[3 * FIN_C];
+  const int c4 = blockIdx.x * FIN_C;
+  const int nch = min(FIN_C, C - c4);
+  double acc[3][FIN_C] = {};
+  fin_rows<3>(parts, nparts, cs, c0 + c4, nch, acc);
+  if (nparts2 > 0) fin_rows<3>(parts2, nparts2, C, c4, nch, acc);
+  fin_block_sum<3>(acc, red, tot);
+  if ((int)threadIdx.x >= nch) return;
+  const int c = c4 + threadIdx.x;
+  const double s1 = tot[threadIdx.x], s2 = tot[FIN_C + threadIdx.x], s3 = tot[2 * FIN_C + threadIdx.x];
   const double a = (double)gamma[c] * (double)rstd[c];
   dgamma[c] = (float)s2;
   dbeta[c] = (float)s1;
@@ -692,7 +733,7 @@ int launch_bn_finalize(const float* parts, int nparts, long count, const float* 
   const float* rp; int rows;
   int rc = reduce_parts(parts, nparts, 2 * C, &rp, &rows, stream, 512);
   if (rc != UNETDC_OK) return rc;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, stream, rp, rows, (double)count, gamma,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FIN_C - 1) / FIN_C), dim3(256), 0, stream, rp, rows, (double)count, gamma,
                      beta, eps, momentum, rm, rv, scale, shift, mean, rstd, C);
   return check_launch("bn_finalize_kernel");
 }
@@ -843,7 +884,7 @@ int launch_bn_bwd(BnBwdParams& p, const float* gamma, float* dgamma, float* dbet
     rc = reduce_parts(parts, nb, 3 * p.C, &rp, &rows, stream, 512);
   }
   if (rc != UNETDC_OK) return rc;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 7) / 8), dim3(256), 0, stream, rp, rows, p.C, 0,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + FIN_C - 1) / FIN_C), dim3(256), 0, stream, rp, rows, p.C, 0,
                      (const float*)nullptr, 0, (double)p.N * p.H * p.W, gamma, p.rstd, dgamma, dbeta, dbias, k, k + p.C,
                      k + 2 * p.C, p.C, frozen ? 1 : 0);
   rc = check_launch("bn_bwd_finalize_kernel");
@@ -899,7 +940,7 @@ int launch_bn_bwd_pool_split(BnBwdParams& p, const float* gamma, float* dgamma, 
   const float* sp; int srows;
   rc = reduce_parts(skip_parts, skip_rows, 3 * skip_cs, &sp, &srows, stream, 512);    // > 512 rows: one stage into the 64 spare rows
   if (rc != UNETDC_OK) return rc;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + 7) / 8), dim3(256), 0, stream, sp, srows, skip_cs, skip_c0, rp, rows,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + FIN_C - 1) / FIN_C), dim3(256), 0, stream, sp, srows, skip_cs, skip_c0, rp, rows,
                      (double)p.N * p.H * p.W, gamma, p.rstd, dgamma, dbeta, dbias, k, k + p.C, k + 2 * p.C, p.C, 0);
   rc = check_launch("bn_bwd_finalize_kernel");
   if (rc != UNETDC_OK) return rc;

@@ -27,6 +27,7 @@
 
 #include "igemm_epilogue16.h"
 #include "kernels.h"
+#include "lds_dma.h"
 
 namespace unetdc {
 
@@ -34,7 +35,11 @@ namespace unetdc {
 constexpr unsigned OOB16 = 0x80000000u;
 
 // WM x WN waves; each wave owns (TMT*16) x 64 outputs (TMT x 4 MFMA 16x16 tiles).
-template <int WM, int WN, int TMT>
+// NS = stages of the LDS ring.  The DMAs are issued from inline asm (lds_dma.h) and waited for by count: with NS = 3 the
+// stage of step s + 2 goes out behind the barrier of step s and has TWO steps of MFMA work to land (L2 -> LDS takes
+// 1.5-2 us for a 48-64 KB stage; one step of a 256 x 128 tile is 0.5-0.9 us of MFMA work); NS = 2 is the round-1 pipeline
+// (issue s + 1 behind the barrier of step s, drain before the next barrier) for the tiles whose three stages do not fit.
+template <int WM, int WN, int TMT, int NS>
 __global__ __launch_bounds__(512, 2) void igemm_dma16_kernel(const IgemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NW = WM * WN;
@@ -42,7 +47,10 @@ __global__ __launch_bounds__(512, 2) void igemm_dma16_kernel(const IgemmParams p
   constexpr int AI = BM / 8 / NW, BI = BN / 8 / NW;
   constexpr int ES = 2, KE = 64;
   constexpr int STAGE = (BM + BN) * 128;
+  constexpr int PER = AI + BI;                     // DMA wave-instructions per wave and stage
   static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile/wave mismatch");
+  static_assert(NS == 2 || NS == 3, "ring depth");
+  static_assert((NS - 2) * PER <= 63, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -52,6 +60,7 @@ __global__ __launch_bounds__(512, 2) void igemm_dma16_kernel(const IgemmParams p
   const int mblk = tile / p.nblocks, nblk = tile - mblk * p.nblocks;
   const int m0 = mblk * BM, n0 = nblk * BN;
   const int HoWo = p.Ho * p.Wo;
+  const unsigned lds_base = lds_addr_of(smem);
 
   const unsigned xbytes = (unsigned)(((long)p.M / HoWo) * p.Hi * p.Wi * p.ldx * ES);
   const unsigned wbytes = (unsigned)((long)p.ntaps * p.Cout * p.Cin * ES);
@@ -130,6 +139,7 @@ __global__ __launch_bounds__(512, 2) void igemm_dma16_kernel(const IgemmParams p
   }
   const int nkc = p.Cin / KE;
   const int nsteps = __popc(tapmask) * nkc;
+  const bool stagger = p.dbg != 1;                 // UNETDC_DMA16_STAGGER=0 (A/B): every wave issues before its MFMAs
 
   // fragment read offsets: row c of a tile, chunk 4*g + rb (swizzle is the same for every 16-row tile)
   const int c16 = lane & 15, rb = lane >> 4;
@@ -156,19 +166,16 @@ __global__ __launch_bounds__(512, 2) void igemm_dma16_kernel(const IgemmParams p
   auto issue = [&](int stage) {
     const int dy = p.offy[lt], dx = p.offx[lt];
     const unsigned dbytes = (unsigned)((dy * p.Wi + dx) * p.ldx * ES + lkc * 128);
-    unsigned char* sbase = smem + stage * STAGE;
+    const unsigned sbase = lds_base + (unsigned)__builtin_amdgcn_readfirstlane(stage) * STAGE;
 #pragma unroll
     for (int j = 0; j < AI; ++j) {
       const int iy = ys[j] + dy, ix = xs[j] + dx;
       const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-      const unsigned voff = ok ? abase[j] + dbytes : OOB16;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, LDS_PTR16(sbase + (wave + NW * j) * 1024), 16, voff, 0, 0, 0);
+      lds_dma16(xr, sbase + (wave + NW * j) * 1024, ok ? abase[j] + dbytes : OOB16, 0u);
     }
-    const unsigned wbytes_t = (unsigned)(lt * p.Cout * p.Cin * ES + lkc * 128);
+    const unsigned wbytes_t = (unsigned)__builtin_amdgcn_readfirstlane((int)(lt * p.Cout * p.Cin * ES + lkc * 128));
 #pragma unroll
-    for (int j = 0; j < BI; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, LDS_PTR16(sbase + BM * 128 + (wave + NW * j) * 1024), 16,
-                                               bbase[j] + wbytes_t, 0, 0, 0);
+    for (int j = 0; j < BI; ++j) lds_dma16(wr, sbase + BM * 128 + (wave + NW * j) * 1024, bbase[j], wbytes_t);
     // K order: 64-channel chunk OUTER, tap INNER.  The nine taps of one chunk re-read (shifted) the same 32 KB of
     // input, back to back, so they hit in the XCD's 4 MB L2; with the tap outer a workgroup streamed its whole
     // 256-pixel x Cin slab between two uses and every tap came from beyond L2 (PMC: 2.1x the algorithmic bytes).
@@ -180,12 +187,23 @@ __global__ __launch_bounds__(512, 2) void igemm_dma16_kernel(const IgemmParams p
     }
   };
 
-  if (nsteps > 0) issue(0);
+  // stages 0 .. NS - 2 up front; iteration s: own pieces of stage s landed (the NS - 2 younger stages may stay in flight) ->
+  // barrier (RAW for stage s, WAR for the buffer of step s - 1) -> issue stage s + NS - 1 into that buffer -> MFMAs of step s
+#pragma unroll
+  for (int k = 0; k < NS - 1; ++k)
+    if (k < nsteps) issue(k);
+  // OPPOSITE PHASES for the two waves of a SIMD (waves w and w + NW / 2): the first half issues its DMAs before its MFMAs, the
+  // second half after them -- while one wave waits for the texture-address unit to take its DMA instructions the other one
+  // feeds the matrix pipe (profiles/r03_dma16_step_decomposition.txt: in lock step the two costs add up, 0.45 + 0.21 us on
+  // 0.70 us per step).  A stage issued late still has one whole step to land: three-stage ring only.
+  const bool late = NS == 3 && stagger && wave >= NW / 2;
+  int cur = 0, fill = NS - 1;
   for (int s = 0; s < nsteps; ++s) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (s + 1 < nsteps) issue((s + 1) & 1);
-    const unsigned char* base = smem + (s & 1) * STAGE;
+    if (NS > 2 && s + NS - 2 < nsteps) wait_vmcnt<(NS - 2) * PER>(); else wait_vmcnt<0>();
+    raw_barrier();
+    const bool more = s + NS - 1 < nsteps;
+    if (more && !late) issue(fill);
+    const unsigned char* base = smem + cur * STAGE;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       u32x4 fa[TMT], fb[4];
@@ -200,6 +218,9 @@ __global__ __launch_bounds__(512, 2) void igemm_dma16_kernel(const IgemmParams p
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
                                                               acc[i][j], 0, 0, 0);
     }
+    if (more && late) issue(fill);
+    cur = cur + 1 == NS ? 0 : cur + 1;
+    fill = fill + 1 == NS ? 0 : fill + 1;
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------------
@@ -250,13 +271,14 @@ __global__ __launch_bounds__(512, 2) void igemm_dma16_kernel(const IgemmParams p
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int WM, int WN, int TMT>
+template <int WM, int WN, int TMT, int NS>
 static int launch_dma16_cfg(IgemmParams& p, hipStream_t stream) {
   constexpr int BM = WM * TMT * 16, BN = WN * 64;
-  constexpr int LDS = 2 * (BM + BN) * 128;
+  constexpr int LDS = NS * (BM + BN) * 128;
+  static_assert(LDS <= 160 * 1024, "ring does not fit");
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma16_kernel<WM, WN, TMT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma16_kernel<WM, WN, TMT, NS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {
       set_error("hipFuncSetAttribute(igemm_dma16_kernel) failed: %s", hipGetErrorString(e));
@@ -269,6 +291,9 @@ static int launch_dma16_cfg(IgemmParams& p, hipStream_t stream) {
   // 16 x 16 pixel blocks as M tiles for strongly dilated 3 x 3 convolutions (header comment): every padded tap-pixel pair is skipped
   static int quad_on = -1;                               // UNETDC_QUAD=0: row-major blocks (A/B measurements)
   if (quad_on < 0) { const char* e = getenv("UNETDC_QUAD"); quad_on = (e && e[0] == '0') ? 0 : 1; }
+  static int stagger = -1;
+  if (stagger < 0) { const char* e = getenv("UNETDC_DMA16_STAGGER"); stagger = (e && e[0] == '0') ? 0 : 1; }
+  p.dbg = stagger ? 0 : 1;
   p.quad_bpr = p.quad_bpi = 0;
   if (quad_on && BM == 256 && p.ntaps == 9 && p.stride == 1 && p.mode != MODE_SHUFFLE && p.Ho == p.Hi && p.Wo == p.Wi &&
       p.offy[8] >= 16 && p.offy[8] % 16 == 0 && p.offx[8] == p.offy[8] && p.Ho % 16 == 0 && p.Wo % 16 == 0 &&
@@ -277,9 +302,9 @@ static int launch_dma16_cfg(IgemmParams& p, hipStream_t stream) {
     p.quad_bpi = (p.Ho / 16) * p.quad_bpr;
   }
   const long nwg = (long)p.mblocks * p.nblocks;
-  hipLaunchKernelGGL((igemm_dma16_kernel<WM, WN, TMT>), dim3((unsigned)nwg), dim3(WM * WN * 64), LDS, stream, p);
+  hipLaunchKernelGGL((igemm_dma16_kernel<WM, WN, TMT, NS>), dim3((unsigned)nwg), dim3(WM * WN * 64), LDS, stream, p);
   char nm[96];
-  snprintf(nm, sizeof(nm), "igemm_dma16_kernel<%d, %d, %d>%s", WM, WN, TMT, p.quad_bpr ? " blocks16x16" : "");
+  snprintf(nm, sizeof(nm), "igemm_dma16_kernel<%d, %d, %d>%s%s", WM, WN, TMT, NS == 3 ? " ring3" : "", p.quad_bpr ? " blocks16x16" : "");
   note_kernel(nm);
   return check_launch("igemm_dma16_kernel");
 }
@@ -293,9 +318,11 @@ bool igemm_dma16_supported(const IgemmParams& p, int dtype) {
 
 // cfg: 1 = 256x256 (8 waves), 2 = 256x128 (8 waves), 3 = 256x64 (4 waves) -- chosen by launch_igemm_dma
 int launch_igemm_dma16(IgemmParams& p, int cfg, hipStream_t stream) {
-  if (cfg == 1) return launch_dma16_cfg<2, 4, 8>(p, stream);
-  if (cfg == 2) return launch_dma16_cfg<4, 2, 4>(p, stream);
-  return launch_dma16_cfg<4, 1, 4>(p, stream);
+  static int ring3 = -1;                                 // UNETDC_DMA16_RING=2: two-stage pipeline everywhere (A/B); 3: also 256 x 64
+  if (ring3 < 0) { const char* e = getenv("UNETDC_DMA16_RING"); ring3 = e ? atoi(e) : 1; }
+  if (cfg == 1) return launch_dma16_cfg<2, 4, 8, 2>(p, stream);              // 3 x 64 KB does not fit
+  if (cfg == 2) return ring3 != 2 ? launch_dma16_cfg<4, 2, 4, 3>(p, stream) : launch_dma16_cfg<4, 2, 4, 2>(p, stream);
+  return ring3 == 3 ? launch_dma16_cfg<4, 1, 4, 3>(p, stream) : launch_dma16_cfg<4, 1, 4, 2>(p, stream);
 }
 
 }  // namespace unetdc
