@@ -56,6 +56,7 @@ struct LatticeParams {
   int stat_rows;              // statistics rows with data = gridDim.x / nblocks (one per workgroup and n-block), 0: per-tile rows
   int mtiles;                 // N * tiles_per_img = M / 256: rows [stat_rows, mtiles) are written as zeros
   int dbg;                    // UNETDC_LAT_DBG (timing experiments only, results invalid): 1 no tap barriers, 2 no DMA waits, 8 no DMA
+  int prio;                   // 1: s_setprio 1 through the tap loops, 0 in the epilogue (UNETDC_LAT_PRIO=0 turns it off: A/B)
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -315,6 +316,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
   };
   float tot_su = 0.f, tot_sq = 0.f;               // lanes tid < BN: running statistics of channel nblk * BN + tid
   auto epilogue = [&](const Item& it) {
+    if (q.prio) __builtin_amdgcn_s_setprio(0);
     bool tile_ok[MT];
     unsigned voff[MT], yoff[MT];
     item_offsets(it, voff, yoff);
@@ -356,12 +358,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
         tot_sq += sq;
       }
     }
+    if (q.prio) __builtin_amdgcn_s_setprio(1);
     zero_acc();
   };
 
   // ---- the pipeline ----------------------------------------------------------------------------------------------------
   // flat step q = 9*chunk + tap over all (item, K chunk) pairs of this workgroup; weights of step q live in ring stage
   // tap % 3 and are issued at step q - 2; the patch of chunk c lives in buffer c % NPB.
+  if (q.prio) __builtin_amdgcn_s_setprio(1);
   Item cur = decode(first), nxt = cur;
   int item = first;
   load_consts(cur.nblk);
@@ -667,6 +671,7 @@ __global__ __launch_bounds__(256, 2) void igemm_lattice_wide_kernel(const IgemmP
   };
   float tot_su = 0.f, tot_sq = 0.f;               // lanes tid < BN: running statistics of channel nblk * BN + tid
   auto epilogue = [&](const Item& it) {
+    if (q.prio) __builtin_amdgcn_s_setprio(0);
     bool tile_ok[MT];
     unsigned voff[MT], yoff[MT];
     item_offsets(it, voff, yoff);
@@ -720,12 +725,18 @@ __global__ __launch_bounds__(256, 2) void igemm_lattice_wide_kernel(const IgemmP
         tot_sq += sq;
       }
     }
+    if (q.prio) __builtin_amdgcn_s_setprio(1);
     zero_acc();
   };
 
   // ---- the pipeline ----------------------------------------------------------------------------------------------------
   // flat step q = 9*chunk + tap; weights of step q live in ring stage q & 1 and are issued behind the barrier of step q - 1;
   // the patch of a chunk is issued behind the last barrier of the previous chunk (single buffer).
+  // Two independent workgroups share every SIMD; VALU / MFMA issue is arbitrated by priority, then age (MI355X_MICROARCH.md,
+  // "Two waves per SIMD").  The tap loops run at priority 1 and the epilogue (300-600 VALU instructions per item) at 0, so
+  // that a workgroup in its MFMA phase is not held up by its neighbour's epilogue: -0.05 ... -0.07 ms per training step,
+  // three of three interleaved pairs (profiles/r03_setprio_ab.txt).
+  if (q.prio) __builtin_amdgcn_s_setprio(1);
   Item cur = decode(first), nxt = cur;
   int item = first;
   load_consts(cur.nblk);
@@ -904,6 +915,9 @@ int launch_igemm_lattice(IgemmParams& p, hipStream_t stream) {
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("UNETDC_LAT_DBG"); dbg = e ? atoi(e) : 0; }
     q.dbg = dbg;
+    static int prio = -1;
+    if (prio < 0) { const char* e = getenv("UNETDC_LAT_PRIO"); prio = (e && e[0] == '0') ? 0 : 1; }
+    q.prio = prio;
   }
   const int nimg = (int)((long)p.M / ((long)p.Ho * p.Wo));
   q.mtiles = nimg * q.tiles_per_img;              // = M / 256
