@@ -339,6 +339,43 @@ def test_bn_relu_fwd_bwd(dtype, pool, case):
         np.testing.assert_allclose(cs.cpu().numpy(), spv[:, 0, c:].double().sum(0).float().cpu().numpy(), rtol=1e-6)
 
 
+@pytest.mark.parametrize("rows,c", [(1, 64), (37, 6), (512, 64), (700, 10), (300, 1024)])
+def test_bn_finalize_many_partial_rows(rows, c):
+    """unetdc_bn_finalize over `rows` partial rows of (sum, sum of squares): one workgroup per four channels, rows strided
+    over its 256 threads, fp64 from the partial sums on -- also channel counts that are not a multiple of four and row counts
+    beyond the 512 that go through the pre-reduction stage (nn.BatchNorm2d training statistics, models/model_2.py:45,52)."""
+    g = gen(23)
+    cnt = 4096 * rows
+    part = torch.zeros((rows + 64) * 2 * c, dtype=torch.float32)
+    pv = part[: rows * 2 * c].view(rows, 2, c)
+    pv[:, 0] = torch.randn(rows, c, generator=g) * 30 + 100        # partial sums of ~4096 values each
+    pv[:, 1] = torch.rand(rows, c, generator=g) * 4000 + 9000
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    rm0, rv0 = torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.5
+    s, q = pv[:, 0].double().sum(0), pv[:, 1].double().sum(0)
+    mean = s / cnt
+    var = (q / cnt - mean * mean).clamp_min(0)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    f32 = dict(device="cuda", dtype=torch.float32)
+    pd = part.cuda()
+    scale, shift, mean_d, rstd_d = (torch.full((c,), float("nan"), **f32) for _ in range(4))
+    rmd, rvd, gd, bd = rm0.cuda(), rv0.cuda(), gamma.cuda(), beta.cuda()
+    call("unetdc_bn_finalize", pd.data_ptr(), rows, cnt, gd.data_ptr(), bd.data_ptr(), 1e-5, 0.1, rmd.data_ptr(),
+         rvd.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean_d.data_ptr(), rstd_d.data_ptr(), c, G.stream())
+    rt = 1e-6 if rows <= 512 else 3e-6                      # > 512 rows: one fp32 pre-reduction stage in front
+    np.testing.assert_allclose(mean_d.cpu().numpy(), mean.float().numpy(), rtol=rt, atol=1e-7)
+    np.testing.assert_allclose(rstd_d.cpu().numpy(), rstd.float().numpy(), rtol=rt)
+    np.testing.assert_allclose(scale.cpu().numpy(), (gamma.double() * rstd).float().numpy(), rtol=4e-6)
+    np.testing.assert_allclose(shift.cpu().numpy(), (beta.double() - mean * gamma.double() * rstd).float().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(rmd.cpu().numpy(), (0.9 * rm0.double() + 0.1 * mean).float().numpy(), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(rvd.cpu().numpy(), (0.9 * rv0.double() + 0.1 * var * cnt / (cnt - 1)).float().numpy(), rtol=2e-6)
+    # bitwise reproducible: the summation order is fixed
+    scale2 = torch.full((c,), float("nan"), **f32)
+    call("unetdc_bn_finalize", pd.data_ptr(), rows, cnt, gd.data_ptr(), bd.data_ptr(), 1e-5, 0.1, None, None,
+         scale2.data_ptr(), shift.data_ptr(), mean_d.data_ptr(), rstd_d.data_ptr(), c, G.stream())
+    assert torch.equal(scale2, scale)
+
+
 @pytest.mark.parametrize("case", [(2, 256, 256, 64, 64, 1), (3, 512, 256, 64, 64, 1), (2, 64, 256, 64, 64, 2), (2, 96, 192, 64, 64, 1),
                                   (2, 128, 128, 128, 64, 1)])
 def test_conv_and_wgrad_fed_from_raw_output_normalise_on_load(case):
