@@ -268,21 +268,27 @@ def hbm_bytes(name, a, es):
     if name == "unetdc_head_bwd":                          # dprobs, probs, a -> da
         n, h, w, c, oc = a[11:16]
         return n * h * w * (2 * c * es + 2 * oc * 4)
-    if name == "unetdc_head_bwd_bnstats":                  # dprobs, probs, [a,] y (of the last stage) -> da
+    if name == "unetdc_head_bwd_bnstats":                  # dprobs, probs, [a,] y (of the last stage) -> [da]
         n, h, w, c, oc = a[20:25]
-        return n * h * w * ((3 if a[2] else 2) * c * es + 2 * oc * 4)
+        return n * h * w * (((2 if a[2] else 1) + (1 if a[5] else 0)) * c * es + 2 * oc * 4)
+    if name == "unetdc_bn_relu_bwd_head":                  # dprobs, probs, y -> dy
+        n, h, w, c = a[19:23]
+        return n * h * w * (2 * c * es + 2 * 4)
     if name == "unetdc_conv3x3_first_fwd":                 # x (fp32 NCHW) -> y
         n, h, w, cin, cout = a[8:13]
         return n * h * w * (cin * 4 + cout * es)
+    if name == "unetdc_conv3x3_first_wgrad_bn":            # x, dz, y -> dW (BatchNorm backward on load)
+        n, h, w, cin, cout = a[13:18]
+        return n * h * w * (cin * 4 + 2 * cout * es)
     if name == "unetdc_conv3x3_first_wgrad":               # x, dy -> dW
         n, h, w, cin, cout = a[6:11]
         return n * h * w * (cin * 4 + cout * es)
     raise KeyError(name)
 
 
-HBM_CALLS = ["unetdc_bn_relu_apply", "unetdc_bn_relu_bwd", "unetdc_head_fwd", "unetdc_head_fwd_bn", "unetdc_head_bwd",
-             "unetdc_head_bwd_bnstats",
-             "unetdc_conv3x3_first_fwd", "unetdc_conv3x3_first_wgrad"]
+HBM_CALLS = ["unetdc_bn_relu_apply", "unetdc_bn_relu_bwd", "unetdc_bn_relu_bwd_head", "unetdc_head_fwd", "unetdc_head_fwd_bn",
+             "unetdc_head_bwd", "unetdc_head_bwd_bnstats",
+             "unetdc_conv3x3_first_fwd", "unetdc_conv3x3_first_wgrad", "unetdc_conv3x3_first_wgrad_bn"]
 
 
 def hbm_leg(step, es, nsteps=3):

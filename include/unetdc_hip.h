@@ -136,6 +136,20 @@ int64_t unetdc_conv3x3_first_wgrad_workspace(int n, int h, int w, int cin, int c
 int unetdc_conv3x3_first_wgrad(const float* x_nchw, const void* dy, int lddy, float* dw, void* workspace,
                                int64_t workspace_bytes, int n, int h, int w, int cin, int cout, int dilation,
                                int dtype, unetdc_stream_t s);
+/* The first layer's weight gradient with the BatchNorm + ReLU backward of its stage applied ON LOAD (models/model_2.py:41-46
+ * under autograd): dz = gradient of the stage's activated output, y = its saved conv output, coeffs [3][cout] from
+ * unetdc_bn_relu_bwd_coeffs (which also finalises dgamma / dbeta / dbias from the partial sums a fused dgrad epilogue left:
+ * unetdc_conv3x3_dgrad_bnstats).  dy = k1 * [a > 0] * dz - k2 - k3 * xhat is formed per loaded chunk, rounded through the
+ * storage type -- bit-identical to unetdc_bn_relu_bwd + unetdc_conv3x3_first_wgrad, without the pass that writes dy and the
+ * one that reads it.  Only when nothing else needs dy (no dL/dx) and for the shapes _supported answers 1 (one input channel,
+ * dilation 1, w % 8 == 0). */
+int unetdc_conv3x3_first_wgrad_bn_supported(int n, int h, int w, int cin, int cout, int dilation, int dtype);
+int unetdc_bn_relu_bwd_coeffs(const float* pre_parts, int pre_nparts, const float* gamma, const float* rstd, float* dgamma,
+                              float* dbeta, float* dbias, float* coeffs, int n, int h, int w, int c, unetdc_stream_t s);
+int unetdc_conv3x3_first_wgrad_bn(const float* x_nchw, const void* dz, int lddz, const void* y, int ldy, const float* scale,
+                                  const float* shift, const float* mean, const float* rstd, const float* coeffs, float* dw,
+                                  void* workspace, int64_t workspace_bytes, int n, int h, int w, int cin, int cout,
+                                  int dilation, int dtype, unetdc_stream_t s);
 /* Gradient with respect to the INPUT image, dL/dx of the module's forward (autograd of the first nn.Conv2d, models/model_2.py:
  * 10,41-44,58; the reference's loops never request it, a saliency-style caller does): dx NCHW fp32 [n][cin][h][w] from the
  * gradient dy [n*h*w][lddy] of the first convolution's output and its fp32 weights in PyTorch layout [cout][cin][3][3]. */
@@ -182,6 +196,16 @@ int unetdc_bn_relu_bwd(const void* dskip, int ldskip, const void* dpool, int ldp
                        const float* gamma, void* dy, int lddy, float* dgamma, float* dbeta, float* dbias,
                        void* workspace, int64_t workspace_bytes, const float* pre_parts, int pre_nparts, int n, int h,
                        int w, int c, int dtype, unetdc_stream_t s);
+/* unetdc_bn_relu_bwd for the stage in front of a ONE-channel head (dec1's second stage, models/model_2.py:76-80): the
+ * gradient of the head's input is dz * w[c] with dz = dprobs * p * (1 - p) per pixel, so it is recomputed from the fp32
+ * [N, 1, H, W] tensors instead of being written by unetdc_head_bwd_bnstats (call that with da = NULL) and read back -- two
+ * activation-sized transfers less per step; rounded through the storage type, i.e. bit-identical to the stored form.
+ * pre_parts / pre_nparts: the sums unetdc_head_bwd_bnstats produced (required). */
+int unetdc_bn_relu_bwd_head(const float* dprobs, const float* probs, const float* head_w, const void* y, int ldy,
+                            const float* scale, const float* shift, const float* mean, const float* rstd,
+                            const float* gamma, void* dy, int lddy, float* dgamma, float* dbeta, float* dbias,
+                            void* workspace, int64_t workspace_bytes, const float* pre_parts, int pre_nparts, int n, int h,
+                            int w, int c, int dtype, unetdc_stream_t s);
 /* BatchNorm with FROZEN statistics under autograd -- model.eval() with gradients enabled, i.e. fine-tuning with fixed
  * running statistics, which the reference module supports through plain autograd (nn.BatchNorm2d in eval mode,
  * models/model_2.py:45,52): unetdc_bn_frozen_affine fills scale / shift / mean / rstd from the running buffers (the conv bias

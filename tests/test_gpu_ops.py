@@ -547,6 +547,143 @@ def test_head_bwd_fused_bn_backward_sums(dtype, shape):
     assert float((got - ref).abs().max()) < float(tol), float((got - ref).abs().max())
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 16, 24), (1, 64, 64), (3, 160, 96)])
+def test_bn_backward_recomputes_the_head_gradient(dtype, shape):
+    """unetdc_head_bwd_bnstats with da = NULL + unetdc_bn_relu_bwd_head (one-channel head, models/model_2.py:76-80): the
+    gradient of the head's input is recomputed per pixel instead of stored -- dy, dgamma, dbeta, dbias and the head's own
+    dw / db are BIT-identical to the stored form (unetdc_head_bwd_bnstats with da + unetdc_bn_relu_bwd)."""
+    import ctypes
+    n, h, w = shape
+    c, oc = 64, 1
+    g = gen(31)
+    y = G.quant(torch.randn(n, c, h, w, generator=g), dtype)
+    gamma = torch.rand(c, generator=g) + 0.5
+    mean, rstd = torch.randn(c, generator=g) * 0.2, torch.rand(c, generator=g) + 0.5
+    scale = gamma * rstd
+    shift = torch.randn(c, generator=g) * 0.3 - mean * scale
+    wt = (torch.randn(oc, c, generator=g) * 0.3).cuda().contiguous()
+    probs = torch.rand(n, oc, h, w, generator=g).cuda()
+    dp = torch.randn(n, oc, h, w, generator=g).cuda()
+    yv = G.to_nhwc(y, dtype)
+    dv = [t.cuda() for t in (scale, shift, mean, rstd, gamma)]
+    nbytes = _lib.load().unetdc_head_bwd_workspace(n, h, w, c, oc, G.DT[dtype])
+    ws = G.workspace(nbytes)
+    nb2 = _lib.load().unetdc_bn_relu_bwd_workspace(n, h, w, c, 0, G.DT[dtype])
+    ws2 = G.workspace(nb2)
+    rows = _lib.load().unetdc_conv3x3_stats_rows(n * h * w, c)
+    f32 = dict(device="cuda", dtype=torch.float32)
+    res = []
+    for stored in (True, False):
+        parts = torch.full(((rows + 64) * 3 * c,), float("nan"), device="cuda")
+        npar = ctypes.c_int(0)
+        dav = G.empty_nhwc(n * h * w, c, dtype)
+        dw, db = torch.full((oc, c), float("nan"), **f32), torch.full((oc,), float("nan"), **f32)
+        call("unetdc_head_bwd_bnstats", dp.data_ptr(), probs.data_ptr(), None, c, wt.data_ptr(),
+             dav.data_ptr() if stored else None, dav.stride(0), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), nbytes,
+             yv.data_ptr(), yv.stride(0), dv[0].data_ptr(), dv[1].data_ptr(), dv[2].data_ptr(), dv[3].data_ptr(),
+             parts.data_ptr(), parts.numel(), ctypes.byref(npar), n, h, w, c, oc, G.DT[dtype], G.stream())
+        dyv = G.empty_nhwc(n * h * w, c, dtype)
+        dgam, dbet, dbias = (torch.full((c,), float("nan"), **f32) for _ in range(3))
+        if stored:
+            call("unetdc_bn_relu_bwd", dav.data_ptr(), dav.stride(0), None, 0, yv.data_ptr(), yv.stride(0), dv[0].data_ptr(),
+                 dv[1].data_ptr(), dv[2].data_ptr(), dv[3].data_ptr(), dv[4].data_ptr(), dyv.data_ptr(), dyv.stride(0),
+                 dgam.data_ptr(), dbet.data_ptr(), dbias.data_ptr(), ws2.data_ptr(), nb2, parts.data_ptr(), npar.value,
+                 n, h, w, c, G.DT[dtype], G.stream())
+        else:
+            call("unetdc_bn_relu_bwd_head", dp.data_ptr(), probs.data_ptr(), wt.data_ptr(), yv.data_ptr(), yv.stride(0),
+                 dv[0].data_ptr(), dv[1].data_ptr(), dv[2].data_ptr(), dv[3].data_ptr(), dv[4].data_ptr(), dyv.data_ptr(),
+                 dyv.stride(0), dgam.data_ptr(), dbet.data_ptr(), dbias.data_ptr(), ws2.data_ptr(), nb2, parts.data_ptr(),
+                 npar.value, n, h, w, c, G.DT[dtype], G.stream())
+        torch.cuda.synchronize()
+        res.append([t.clone() for t in (dyv, dgam, dbet, dbias, dw, db)])
+    for a, b in zip(*res):
+        assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+    # and it is the right gradient: dy against autograd of relu(batch_norm) on the CPU for the incoming gradient dz * w
+    dz = (dp * probs * (1 - probs)).cpu()
+    da_ref = G.quant(dz * wt.cpu().view(1, c, 1, 1), dtype)
+    yr = y.clone().requires_grad_(True)
+    a_ref = torch.relu((yr - mean.view(1, c, 1, 1)) * rstd.view(1, c, 1, 1) * gamma.view(1, c, 1, 1)
+                       + (shift + mean * scale).view(1, c, 1, 1))
+    gate = (a_ref > 0).float()
+    gh = da_ref * gate
+    xh = ((y - mean.view(1, c, 1, 1)) * rstd.view(1, c, 1, 1)).double()
+    m = n * h * w
+    k1 = (gamma * rstd).double().view(1, c, 1, 1)
+    dy_ref = k1 * (gh.double() - gh.double().sum((0, 2, 3), keepdim=True) / m
+                   - xh * (gh.double() * xh).sum((0, 2, 3), keepdim=True) / m)
+    assert rel(G.from_nhwc(res[1][0], n, h, w), dy_ref.float()) < (2e-5 if dtype == "f32" else 8e-3)
+    with pytest.raises(_lib.UnetdcError, match="da may be NULL only"):
+        call("unetdc_head_bwd_bnstats", dp.data_ptr(), probs.data_ptr(), None, c, wt.data_ptr(), None, c, dw.data_ptr(),
+             db.data_ptr(), ws.data_ptr(), nbytes, yv.data_ptr(), yv.stride(0), dv[0].data_ptr(), dv[1].data_ptr(),
+             dv[2].data_ptr(), dv[3].data_ptr(), parts.data_ptr(), parts.numel(), ctypes.byref(npar), n, h, w, c, 2,
+             G.DT[dtype], G.stream())
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 16, 24), (1, 64, 64), (3, 40, 96)])
+def test_first_wgrad_applies_batchnorm_backward_on_load(dtype, shape):
+    """unetdc_bn_relu_bwd_coeffs + unetdc_conv3x3_first_wgrad_bn (enc1.0 with one input channel, models/model_2.py:10,41-46
+    under autograd) == unetdc_bn_relu_bwd + unetdc_conv3x3_first_wgrad, bit for bit: dw, dgamma, dbeta, dbias."""
+    n, h, w = shape
+    cin, c = 1, 64
+    assert _lib.load().unetdc_conv3x3_first_wgrad_bn_supported(n, h, w, cin, c, 1, G.DT[dtype]) == 1
+    assert _lib.load().unetdc_conv3x3_first_wgrad_bn_supported(n, h, w, 3, c, 1, G.DT[dtype]) == 0
+    g = gen(37)
+    x = torch.randn(n, cin, h, w, generator=g).cuda().contiguous()
+    y = G.quant(torch.randn(n, c, h, w, generator=g), dtype)
+    dz = G.quant(torch.randn(n, c, h, w, generator=g), dtype)
+    gamma = torch.rand(c, generator=g) + 0.5
+    mean, rstd = torch.randn(c, generator=g) * 0.2, torch.rand(c, generator=g) + 0.5
+    scale = gamma * rstd
+    shift = torch.randn(c, generator=g) * 0.3 - mean * scale
+    yv, dzv = G.to_nhwc(y, dtype), G.to_nhwc(dz, dtype)
+    dv = [t.cuda() for t in (scale, shift, mean, rstd, gamma)]
+    # the sums a fused dgrad epilogue would have left, as two partial rows
+    yq, dq = yv.float().cpu()[:, :c].double(), dzv.float().cpu()[:, :c].double()
+    gate = (yq * scale.double() + shift.double()) > 0
+    xh = (yq - mean.double()) * rstd.double()
+    gh = torch.where(gate, dq, torch.zeros_like(dq))
+    rows = 2
+    parts = torch.zeros((rows + 64) * 3 * c, device="cuda")
+    pv = parts[: rows * 3 * c].view(rows, 3, c)
+    for r in range(rows):
+        sel = slice(r, None, rows)
+        pv[r, 0], pv[r, 1], pv[r, 2] = gh[sel].sum(0).float().cuda(), (gh[sel] * xh[sel]).sum(0).float().cuda(), xh[sel].sum(0).float().cuda()
+    f32 = dict(device="cuda", dtype=torch.float32)
+    nb = _lib.load().unetdc_bn_relu_bwd_workspace(n, h, w, c, 0, G.DT[dtype])
+    ws = G.workspace(nb)
+    nbw = _lib.load().unetdc_conv3x3_first_wgrad_workspace(n, h, w, cin, c)
+    wsw = G.workspace(nbw)
+    # two-pass form
+    dyv = G.empty_nhwc(n * h * w, c, dtype)
+    a = [torch.full((c,), float("nan"), **f32) for _ in range(3)]
+    call("unetdc_bn_relu_bwd", dzv.data_ptr(), dzv.stride(0), None, 0, yv.data_ptr(), yv.stride(0), dv[0].data_ptr(),
+         dv[1].data_ptr(), dv[2].data_ptr(), dv[3].data_ptr(), dv[4].data_ptr(), dyv.data_ptr(), dyv.stride(0), a[0].data_ptr(),
+         a[1].data_ptr(), a[2].data_ptr(), ws.data_ptr(), nb, parts.data_ptr(), rows, n, h, w, c, G.DT[dtype], G.stream())
+    dw_a = torch.full((c, cin, 3, 3), float("nan"), **f32)
+    call("unetdc_conv3x3_first_wgrad", x.data_ptr(), dyv.data_ptr(), dyv.stride(0), dw_a.data_ptr(), wsw.data_ptr(), nbw,
+         n, h, w, cin, c, 1, G.DT[dtype], G.stream())
+    # on-load form
+    b = [torch.full((c,), float("nan"), **f32) for _ in range(3)]
+    coef = torch.full((3 * c,), float("nan"), **f32)
+    call("unetdc_bn_relu_bwd_coeffs", parts.data_ptr(), rows, dv[4].data_ptr(), dv[3].data_ptr(), b[0].data_ptr(), b[1].data_ptr(),
+         b[2].data_ptr(), coef.data_ptr(), n, h, w, c, G.stream())
+    dw_b = torch.full((c, cin, 3, 3), float("nan"), **f32)
+    call("unetdc_conv3x3_first_wgrad_bn", x.data_ptr(), dzv.data_ptr(), dzv.stride(0), yv.data_ptr(), yv.stride(0),
+         dv[0].data_ptr(), dv[1].data_ptr(), dv[2].data_ptr(), dv[3].data_ptr(), coef.data_ptr(), dw_b.data_ptr(), wsw.data_ptr(),
+         nbw, n, h, w, cin, c, 1, G.DT[dtype], G.stream())
+    torch.cuda.synchronize()
+    assert torch.isfinite(dw_b).all() and torch.equal(dw_a, dw_b)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    # and dw is the weight gradient of the convolution for that dy (CPU fp32 reference)
+    dy_ref = G.from_nhwc(dyv, n, h, w)
+    wref = torch.zeros(c, cin, 3, 3, requires_grad=True)
+    F.conv2d(x.cpu(), wref, padding=1).backward(dy_ref)
+    assert rel(dw_b.cpu(), wref.grad) < 1e-4
+
+
 def test_argument_errors_are_reported():
     """Error behaviour of the boundary: bad shapes return a negative code + message, no crash."""
     x = torch.zeros(64, 48, device="cuda")

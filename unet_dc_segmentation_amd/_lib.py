@@ -52,6 +52,10 @@ SIGNATURES = {
     "unetdc_bn_relu_bwd_workspace": (L, [I, I, I, I, I, I]),
     "unetdc_bn_relu_bwd": (I, [P, I, P, I, P, I, P, P, P, P, P, P, I, P, P, P, P, L, P, I, I, I, I, I, I, P]),
     "unetdc_bn_frozen_affine": (I, [P, P, P, P, F, P, P, P, P, I, P]),
+    "unetdc_bn_relu_bwd_head": (I, [P, P, P, P, I, P, P, P, P, P, P, I, P, P, P, P, L, P, I, I, I, I, I, I, P]),
+    "unetdc_conv3x3_first_wgrad_bn_supported": (I, [I, I, I, I, I, I, I]),
+    "unetdc_bn_relu_bwd_coeffs": (I, [P, I, P, P, P, P, P, P, I, I, I, I, P]),
+    "unetdc_conv3x3_first_wgrad_bn": (I, [P, P, I, P, I, P, P, P, P, P, P, P, L, I, I, I, I, I, I, I, P]),
     "unetdc_bn_relu_bwd_frozen": (I, [P, I, P, I, P, I, P, P, P, P, P, P, I, P, P, P, P, L, P, I, I, I, I, I, I, P]),
     "unetdc_bn_relu_bwd_pool_split": (I, [P, I, P, I, P, I, P, P, P, P, P, P, I, P, P, P, P, L, P, I, I, I, I, I, I, I, I, P]),
     "unetdc_parts_colsum": (I, [P, I, I, I, I, P, P]),

@@ -279,6 +279,28 @@ int unetdc_conv3x3_first_wgrad(const float* x_nchw, const void* dy, int lddy, fl
   return launch_first_wgrad(p, dw, workspace, (long)workspace_bytes, dtype, (hipStream_t)s);
 }
 
+int unetdc_conv3x3_first_wgrad_bn_supported(int n, int h, int w, int cin, int cout, int dilation, int dtype) {
+  return first_wgrad_bn_supported(n, h, w, cin, cout, dilation, dtype) ? 1 : 0;
+}
+
+int unetdc_conv3x3_first_wgrad_bn(const float* x_nchw, const void* dz, int lddz, const void* y, int ldy, const float* scale,
+                                  const float* shift, const float* mean, const float* rstd, const float* coeffs, float* dw,
+                                  void* workspace, int64_t workspace_bytes, int n, int h, int w, int cin, int cout,
+                                  int dilation, int dtype, unetdc_stream_t s) {
+  GEOM_CHECK(n, h, w);
+  UNETDC_REQUIRE(y != nullptr, "first_wgrad_bn: null saved output");
+  FirstWgradParams p{};
+  p.x = x_nchw; p.dy = dz; p.N = n; p.H = h; p.W = w; p.Cin = cin; p.Cout = cout; p.lddy = lddz; p.dil = dilation;
+  p.bn_y = y; p.bn_ldy = ldy; p.bn_scale = scale; p.bn_shift = shift; p.bn_mean = mean; p.bn_rstd = rstd; p.bn_k = coeffs;
+  return launch_first_wgrad(p, dw, workspace, (long)workspace_bytes, dtype, (hipStream_t)s);
+}
+
+int unetdc_bn_relu_bwd_coeffs(const float* pre_parts, int pre_nparts, const float* gamma, const float* rstd, float* dgamma,
+                              float* dbeta, float* dbias, float* coeffs, int n, int h, int w, int c, unetdc_stream_t s) {
+  GEOM_CHECK(n, h, w);
+  return launch_bn_bwd_coeffs(pre_parts, pre_nparts, (long)n * h * w, gamma, rstd, dgamma, dbeta, dbias, coeffs, c, (hipStream_t)s);
+}
+
 int unetdc_conv3x3_first_dgrad(const void* dy, int lddy, const float* w, float* dx_nchw, int n, int h, int wd, int cin,
                                int cout, int dilation, int dtype, unetdc_stream_t s) {
   GEOM_CHECK(n, h, wd);
@@ -360,6 +382,21 @@ int unetdc_bn_relu_bwd(const void* dskip, int ldskip, const void* dpool, int ldp
   BnBwdParams p{};
   p.dskip = dskip; p.dpool = dpool; p.y = y; p.dy = dy; p.scale = scale; p.shift = shift; p.mean = mean; p.rstd = rstd;
   p.N = n; p.H = h; p.W = w; p.C = c; p.lds = ldskip; p.ldp = ldpool; p.ldy = ldy; p.lddy = lddy;
+  return launch_bn_bwd(p, gamma, dgamma, dbeta, dbias, workspace, (long)workspace_bytes, pre_parts, pre_nparts, dtype,
+                       (hipStream_t)s);
+}
+
+int unetdc_bn_relu_bwd_head(const float* dprobs, const float* probs, const float* head_w, const void* y, int ldy,
+                            const float* scale, const float* shift, const float* mean, const float* rstd,
+                            const float* gamma, void* dy, int lddy, float* dgamma, float* dbeta, float* dbias,
+                            void* workspace, int64_t workspace_bytes, const float* pre_parts, int pre_nparts, int n, int h,
+                            int w, int c, int dtype, unetdc_stream_t s) {
+  GEOM_CHECK(n, h, w);
+  BnBwdParams p{};
+  p.head_dprobs = dprobs; p.head_probs = probs; p.head_w = head_w;
+  p.y = y; p.dy = dy; p.scale = scale; p.shift = shift; p.mean = mean; p.rstd = rstd;
+  p.N = n; p.H = h; p.W = w; p.C = c; p.ldy = ldy; p.lddy = lddy;
+  UNETDC_REQUIRE(head_w != nullptr, "bn_relu_bwd_head: null head weights");
   return launch_bn_bwd(p, gamma, dgamma, dbeta, dbias, workspace, (long)workspace_bytes, pre_parts, pre_nparts, dtype,
                        (hipStream_t)s);
 }

@@ -218,8 +218,12 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const ApplyParams p)
 // The pool arg-max is recomputed from y exactly as the forward pass saw it (values rounded through
 // the storage type, first maximum in row-major window order: ATen's tie rule).
 // ================================================================================================
-template <typename T, bool POOL, bool APPLY>
+// HEAD (non-pooled apply pass only): the incoming gradient is recomputed from the head's dprobs / probs / weight row
+// (BnBwdParams::head_w) -- a template parameter, because the extra registers and the branch cost the plain form 40 % as a
+// run-time switch
+template <typename T, bool POOL, bool APPLY, bool HEAD = false>
 __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdParams p) {
+  static_assert(!HEAD || (!POOL && APPLY), "head form: non-pooled apply pass");
   constexpr int EPC = Chunk<T>::N;
   __shared__ float red[256 * 3 * EPC];
   const int cpp = p.C / EPC;
@@ -240,14 +244,16 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdParams p) {
   T* __restrict__ dyg = reinterpret_cast<T*>(p.dy);
   (void)nseg;
 
-  float sc[EPC], sh[EPC], mu[EPC], rs[EPC], k1[EPC], k2[EPC], k3[EPC];
+  float sc[EPC], sh[EPC], mu[EPC], rs[EPC], k1[EPC], k2[EPC], k3[EPC], hw[EPC];
   float s1[EPC], s2[EPC], s3[EPC];
 #pragma unroll
   for (int e = 0; e < EPC; ++e) {
     s1[e] = s2[e] = s3[e] = 0.f;
+    hw[e] = 0.f;
     if (active) {
       sc[e] = p.scale[c0 + e]; sh[e] = p.shift[c0 + e]; mu[e] = p.mean[c0 + e]; rs[e] = p.rstd[c0 + e];
       if (APPLY) { k1[e] = p.k1[c0 + e]; k2[e] = p.k2[c0 + e]; k3[e] = p.k3[c0 + e]; }
+      if (HEAD) hw[e] = p.head_w[c0 + e];
     }
   }
   if (active) {
@@ -255,7 +261,14 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdParams p) {
       if (!POOL) {
         float yv[EPC], g[EPC];
         Chunk<T>::unpack(ld16(yg + q * p.ldy + c0), yv);
-        Chunk<T>::unpack(ld16(sg + q * p.lds + c0), g);
+        if (HEAD) {                                        // gradient of the head's input, recomputed (see BnBwdParams)
+          const float pr = p.head_probs[q];
+          const float dz = p.head_dprobs[q] * pr * (1.f - pr);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) g[e] = round_through<T>(dz * hw[e]);
+        } else {
+          Chunk<T>::unpack(ld16(sg + q * p.lds + c0), g);
+        }
         float out[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
@@ -519,7 +532,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadParams p) {
           d[e] = (oc > 0 ? d[e] : 0.f) + dz * wv[e];
         }
         if (cl == 0) gb += dz;
-        st16(dag + pix[u] * p.ldda + cl * EPC, Chunk<T>::pack(d));
+        if (dag) st16(dag + pix[u] * p.ldda + cl * EPC, Chunk<T>::pack(d));     // null: the consumer recomputes it (BnBwdParams::head_w)
         if (BN && last) {
 #pragma unroll
           for (int e = 0; e < EPC; ++e) {
@@ -847,12 +860,15 @@ int launch_bn_bwd(BnBwdParams& p, const float* gamma, float* dgamma, float* dbet
                   long workspace_bytes, const float* pre_parts, int pre_nparts, int dtype, hipStream_t stream, bool frozen) {
   const int epc = dtype == UNETDC_BF16 ? 8 : 4;
   UNETDC_REQUIRE(dtype == UNETDC_F32 || dtype == UNETDC_BF16, "bn_bwd: bad dtype %d", dtype);
-  UNETDC_REQUIRE(p.y && p.dy && (p.dskip || p.dpool), "bn_bwd: null tensor");
+  UNETDC_REQUIRE(p.y && p.dy && (p.dskip || p.dpool || p.head_w), "bn_bwd: null tensor");
+  if (p.head_w)
+    UNETDC_REQUIRE(!p.dskip && !p.dpool && p.head_dprobs && p.head_probs && pre_parts,
+                   "bn_bwd (head): needs dprobs, probs and the sums from unetdc_head_bwd_bnstats, and no stored gradient");
   UNETDC_REQUIRE(p.scale && p.shift && p.mean && p.rstd && gamma && dgamma && dbeta && workspace, "bn_bwd: null pointer");
   UNETDC_REQUIRE(p.C % epc == 0 && p.ldy % epc == 0 && p.lddy % epc == 0, "bn_bwd: C/ld not chunk aligned");
   const bool pool = p.dpool != nullptr;
   if (pool) UNETDC_REQUIRE(p.H % 2 == 0 && p.W % 2 == 0 && p.ldp % epc == 0, "bn_bwd: pooling needs even H, W");
-  if (!pool) UNETDC_REQUIRE(p.dskip != nullptr, "bn_bwd: gradient missing");
+  if (!pool) UNETDC_REQUIRE(p.dskip != nullptr || p.head_w != nullptr, "bn_bwd: gradient missing");
   if (p.dskip) UNETDC_REQUIRE(p.lds % epc == 0, "bn_bwd: lds not chunk aligned");
   if (pre_parts) UNETDC_REQUIRE(!pool && pre_nparts > 0, "bn_bwd: precomputed partial sums need the non-pooled form");
   const int cpp = p.C / epc;
@@ -891,9 +907,30 @@ int launch_bn_bwd(BnBwdParams& p, const float* gamma, float* dgamma, float* dbet
   if (rc != UNETDC_OK) return rc;
   const long items = Q * cpp;
   const dim3 grid2(grid_for(items, 256) > 4096 ? 4096 : grid_for(items, 256), (cpp + seg - 1) / seg);
+  if (p.head_w) {
+    if (dtype == UNETDC_BF16) hipLaunchKernelGGL((bn_bwd_kernel<bf16_t, false, true, true>), grid2, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((bn_bwd_kernel<float, false, true, true>), grid2, dim3(256), 0, stream, p);
+    return check_launch("bn_bwd_kernel(apply, head)");
+  }
   if (dtype == UNETDC_BF16) launch_bn_bwd_k<bf16_t>(p, pool, true, grid2, stream);
   else launch_bn_bwd_k<float>(p, pool, true, grid2, stream);
   return check_launch("bn_bwd_kernel(apply)");
+}
+
+// Finalisation alone: dgamma / dbeta / dbias and the three per-channel coefficients of the apply arithmetic
+// (dy = k1 * dyhat - k2 - k3 * xhat) into coeffs[3][C], from sums a producer kernel left as partial rows -- for a consumer
+// that applies them itself (first-layer weight gradient, first_conv.hip)
+int launch_bn_bwd_coeffs(const float* pre_parts, int pre_nparts, long count, const float* gamma, const float* rstd, float* dgamma,
+                         float* dbeta, float* dbias, float* coeffs, int C, hipStream_t stream) {
+  UNETDC_REQUIRE(pre_parts && pre_nparts > 0 && gamma && rstd && dgamma && dbeta && coeffs && C > 0 && count > 0,
+                 "bn_bwd_coeffs: null pointer / empty problem");
+  const float* rp; int rows;
+  int rc = reduce_parts(pre_parts, pre_nparts, 3 * C, &rp, &rows, stream, 512);
+  if (rc != UNETDC_OK) return rc;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_C - 1) / FIN_C), dim3(256), 0, stream, rp, rows, C, 0,
+                     (const float*)nullptr, 0, (double)count, gamma, rstd, dgamma, dbeta, dbias, coeffs, coeffs + C, coeffs + 2 * C,
+                     C, 0);
+  return check_launch("bn_bwd_finalize_kernel");
 }
 
 // Pooled encoder stage whose gradient is  dskip + scatter(dpool):  the sums are linear in the gradient, so the dskip part
@@ -1002,9 +1039,12 @@ int launch_head_bwd(HeadParams& p, float* dw, float* db, void* workspace, long w
                     hipStream_t stream, int* bn_nparts, long bn_parts_floats) {
   int rc = check_head(p, dtype);
   if (rc != UNETDC_OK) return rc;
-  UNETDC_REQUIRE(p.dprobs && p.da && dw && db && workspace, "head_bwd: null pointer");
+  UNETDC_REQUIRE(p.dprobs && dw && db && workspace, "head_bwd: null pointer");
   const int epc = dtype == UNETDC_BF16 ? 8 : 4;
-  UNETDC_REQUIRE(p.ldda % epc == 0, "head_bwd: ldda not chunk aligned");
+  // da == NULL: the gradient of the head's input is not stored (one output channel, fused BatchNorm-backward sums: the
+  // stage's backward pass recomputes it, unetdc_bn_relu_bwd_head)
+  UNETDC_REQUIRE(p.da || (p.OC == 1 && p.bn_y), "head_bwd: da may be NULL only with one output channel and the fused sums");
+  UNETDC_REQUIRE(!p.da || p.ldda % epc == 0, "head_bwd: ldda not chunk aligned");
   int nb = head_blocks((long)p.N * p.H * p.W, p.C / epc);
   const bool bn = p.bn_y != nullptr;
   UNETDC_REQUIRE(bn || p.a, "head_bwd: null activation");

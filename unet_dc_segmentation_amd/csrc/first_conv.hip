@@ -168,7 +168,10 @@ __global__ __launch_bounds__(256) void first_conv_wgrad_kernel(const FirstWgradP
 // traffic is dY.  Here a lane owns 8 channels and walks RUNS of 8 consecutive pixels of one image row: the 3 x 10 input window
 // of a run is loaded once (two float4 + two edge values per row: 12 loads per 8 pixels instead of 72) and slides through
 // registers; the eight dY chunks of a run are issued together.
-template <typename T>
+// BN: the BatchNorm + ReLU backward of the stage on load (FirstWgradParams::bn_*): the stand-alone pass that would read y and
+// the activation gradient and write dy -- three activation-sized transfers at full resolution -- is not run at all; this
+// kernel reads y next to the gradient instead (one more), two pixels at a time to stay inside the register file.
+template <typename T, bool BN>
 __global__ __launch_bounds__(256) void first_wgrad_rows_kernel(const FirstWgradParams p) {
   extern __shared__ __attribute__((aligned(16))) float red[];    // [4 waves][G][72]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -178,11 +181,21 @@ __global__ __launch_bounds__(256) void first_wgrad_rows_kernel(const FirstWgradP
   const int HW = p.H * p.W, rpr = p.W / 8;
   const long runs = (long)p.N * p.H * rpr;
   const T* __restrict__ dyg = reinterpret_cast<const T*>(p.dy);
+  const T* __restrict__ yg = reinterpret_cast<const T*>(p.bn_y);
   float acc[9][8];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+  float sc[8], sh[8], mu[8], rs[8], k1[8], k2[8], k3[8];
+  if (BN) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = g * 8 + e;
+      sc[e] = p.bn_scale[c]; sh[e] = p.bn_shift[c]; mu[e] = p.bn_mean[c]; rs[e] = p.bn_rstd[c];
+      k1[e] = p.bn_k[c]; k2[e] = p.bn_k[p.Cout + c]; k3[e] = p.bn_k[2 * p.Cout + c];
+    }
+  }
 
   for (long r = (long)blockIdx.x * PPB + pl; r < runs; r += (long)gridDim.x * PPB) {
     const int n = (int)(r / ((long)p.H * rpr));
@@ -202,19 +215,37 @@ __global__ __launch_bounds__(256) void first_wgrad_rows_kernel(const FirstWgradP
       xw[ky][5] = b.x * m; xw[ky][6] = b.y * m; xw[ky][7] = b.z * m; xw[ky][8] = b.w * m; xw[ky][9] = rr * m;
     }
     const long pix0 = ((long)n * p.H + y) * p.W + x0;
+    constexpr int PB = BN ? 2 : 4;                         // pixels' chunks in flight at a time (register budget)
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {                       // four pixels' chunks in flight at a time (register budget)
-      float d[4][8];
+    for (int hf = 0; hf < 8 / PB; ++hf) {
+      float d[PB][8];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < PB; ++i)
 #pragma unroll
         for (int q = 0; q < 8 / Chunk<T>::N; ++q)
-          Chunk<T>::unpack(ld16(dyg + (pix0 + 4 * hf + i) * p.lddy + g * 8 + q * Chunk<T>::N), d[i] + q * Chunk<T>::N);
+          Chunk<T>::unpack(ld16(dyg + (pix0 + PB * hf + i) * p.lddy + g * 8 + q * Chunk<T>::N), d[i] + q * Chunk<T>::N);
+      if (BN) {
+        float yv[PB][8];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < PB; ++i)
+#pragma unroll
+          for (int q = 0; q < 8 / Chunk<T>::N; ++q)
+            Chunk<T>::unpack(ld16(yg + (pix0 + PB * hf + i) * p.bn_ldy + g * 8 + q * Chunk<T>::N), yv[i] + q * Chunk<T>::N);
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {                      // bn_bwd_kernel's apply arithmetic, operation for operation
+            const float nrm = fmaf(yv[i][e], sc[e], sh[e]);
+            const float gh = nrm > 0.f ? d[i][e] : 0.f;
+            const float xh = (yv[i][e] - mu[e]) * rs[e];
+            d[i][e] = round_through<T>(fmaf(k1[e], gh, -k2[e]) - k3[e] * xh);
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < PB; ++i)
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-          const float xv = xw[t / 3][4 * hf + i + t % 3];
+          const float xv = xw[t / 3][PB * hf + i + t % 3];
 #pragma unroll
           for (int e = 0; e < 8; ++e) acc[t][e] = fmaf(xv, d[i][e], acc[t][e]);
         }
@@ -302,6 +333,16 @@ static long first_rows_blocks(long P, int Cout) {          // row-run kernel: on
   const long ppb = 256 / (Cout / 8);
   long nb = (P / 8 + ppb - 1) / ppb;
   return nb > FIRST_ROWS_MAXB ? FIRST_ROWS_MAXB : (nb < 1 ? 1 : nb);
+}
+
+// One input channel only: the row-run kernel makes one pass over dY PER input channel, and with the BatchNorm backward on load
+// every pass would also re-read y.
+bool first_wgrad_bn_supported(int N, int H, int W, int Cin, int Cout, int dil, int dtype) {
+  static int off = -1;                                   // UNETDC_FIRST_ROWS=0 also turns this form off (it is the row-run kernel)
+  if (off < 0) { const char* e = getenv("UNETDC_FIRST_ROWS"); off = (e && e[0] == '0') ? 1 : 0; }
+  (void)N; (void)H;
+  return !off && (dtype == UNETDC_F32 || dtype == UNETDC_BF16) && Cin == 1 && dil == 1 && W % 8 == 0 && Cout % 8 == 0 &&
+         Cout / 8 <= 16 && 64 % (Cout / 8) == 0;
 }
 
 long first_wgrad_workspace_bytes(long P, int Cin, int Cout) {
@@ -400,6 +441,29 @@ int launch_first_wgrad(FirstWgradParams& p, float* dw, void* workspace, long wor
   UNETDC_REQUIRE(p.Cin >= 1 && p.Cin <= 8, "first_wgrad: Cin=%d unsupported", p.Cin);
   UNETDC_REQUIRE(p.Cout % 8 == 0 && p.Cout / 8 <= 16 && 64 % (p.Cout / 8) == 0, "first_wgrad: Cout=%d unsupported", p.Cout);
   const long P = (long)p.N * p.H * p.W;
+  if (p.bn_y) {                                          // BatchNorm backward on load: the row-run kernel only
+    UNETDC_REQUIRE(p.bn_scale && p.bn_shift && p.bn_mean && p.bn_rstd && p.bn_k, "first_wgrad (bn): null pointer");
+    UNETDC_REQUIRE(first_wgrad_bn_supported(p.N, p.H, p.W, p.Cin, p.Cout, p.dil, dtype) && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0 &&
+                       p.bn_ldy % (dtype == UNETDC_BF16 ? 8 : 4) == 0,
+                   "first_wgrad (bn): shape not supported (ask unetdc_conv3x3_first_wgrad_bn_supported)");
+    const long nr = first_rows_blocks(P, p.Cout);
+    const long need_r = nr * p.Cin * 9 * p.Cout * 4;
+    if (need_r > workspace_bytes) {
+      set_error("first_wgrad (bn): workspace too small (%ld < %ld bytes)", workspace_bytes, need_r);
+      return UNETDC_EWORKSPACE;
+    }
+    p.part = reinterpret_cast<float*>(workspace);
+    const size_t lds_r = (size_t)4 * (p.Cout / 8) * 72 * 4;
+    if (dtype == UNETDC_BF16)
+      hipLaunchKernelGGL((first_wgrad_rows_kernel<bf16_t, true>), dim3((unsigned)nr, p.Cin), dim3(256), lds_r, stream, p);
+    else
+      hipLaunchKernelGGL((first_wgrad_rows_kernel<float, true>), dim3((unsigned)nr, p.Cin), dim3(256), lds_r, stream, p);
+    int rc = check_launch("first_wgrad_rows_kernel(bn)");
+    if (rc != UNETDC_OK) return rc;
+    const int n = p.Cin * 9 * p.Cout;
+    hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3((n + 7) / 8), dim3(256), 0, stream, p.part, dw, (int)nr, p.Cin, p.Cout);
+    return check_launch("first_wgrad_reduce_kernel");
+  }
   const bool mfma = first_wgrad_mfma(P, p.Cin, p.Cout);
   long nb = first_blocks(P, p.Cout);
   if (nb > 512) nb = 512;
@@ -424,9 +488,9 @@ int launch_first_wgrad(FirstWgradParams& p, float* dw, void* workspace, long wor
     const long nr = first_rows_blocks(P, p.Cout);
     if (nr * p.Cin * 9 * p.Cout * 4 <= workspace_bytes) {
       if (dtype == UNETDC_BF16)
-        hipLaunchKernelGGL(first_wgrad_rows_kernel<bf16_t>, dim3((unsigned)nr, p.Cin), dim3(256), lds, stream, p);
+        hipLaunchKernelGGL((first_wgrad_rows_kernel<bf16_t, false>), dim3((unsigned)nr, p.Cin), dim3(256), lds, stream, p);
       else
-        hipLaunchKernelGGL(first_wgrad_rows_kernel<float>, dim3((unsigned)nr, p.Cin), dim3(256), lds, stream, p);
+        hipLaunchKernelGGL((first_wgrad_rows_kernel<float, false>), dim3((unsigned)nr, p.Cin), dim3(256), lds, stream, p);
       int rc = check_launch("first_wgrad_rows_kernel");
       if (rc != UNETDC_OK) return rc;
       const int n = p.Cin * 9 * p.Cout;

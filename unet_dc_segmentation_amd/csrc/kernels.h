@@ -77,8 +77,16 @@ struct FirstWgradParams {
   const void* dy;     // [P][lddy] T
   float* part;        // [gridDim.x][Cin][9][Cout]
   int N, H, W, Cin, Cout, lddy, dil;
+  // "bn" form (row-run kernel, Cin = 1): `dy` is the gradient of the stage's ACTIVATED output and the BatchNorm + ReLU backward
+  // of the stage is applied on load, dy = k1 * [a > 0] * dz - k2 - k3 * xhat rounded through the storage type (exactly what the
+  // stand-alone pass would have stored) from the saved conv output y and the coefficients of unetdc_bn_relu_bwd_coeffs
+  const void* bn_y; int bn_ldy;
+  const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_rstd; const float* bn_k;   // bn_k: [3][Cout]
 };
 int launch_first_fwd(FirstParams& p, int dtype, hipStream_t stream);
+bool first_wgrad_bn_supported(int N, int H, int W, int Cin, int Cout, int dil, int dtype);
+int launch_bn_bwd_coeffs(const float* pre_parts, int pre_nparts, long count, const float* gamma, const float* rstd, float* dgamma,
+                         float* dbeta, float* dbias, float* coeffs, int C, hipStream_t stream);
 int first_conv_mblocks(long P, int Cin, int Cout);
 bool first_mfma_supported(long P, int Cin, int Cout);
 int first_mfma_mblocks(long P);
@@ -102,6 +110,10 @@ struct BnBwdParams {
   const float* k1; const float* k2; const float* k3;
   float* parts;            // [gridDim.x][3][C]
   int N, H, W, C, lds, ldp, ldy, lddy;
+  // the stage feeds the 1 x 1 head with ONE output channel: its activation gradient is dz * w[c], dz = dprobs * p * (1 - p)
+  // per pixel -- recomputed here from the fp32 [N, 1, H, W] tensors instead of being stored by the head backward and read
+  // back (non-pooled apply pass only; rounded through the storage type like the stored tensor was)
+  const float* head_dprobs; const float* head_probs; const float* head_w;
 };
 struct HeadParams {
   const void* a; const float* w; const float* b; float* probs;

@@ -59,6 +59,14 @@ FUSE_BNIN = os.environ.get("UNETDC_FUSE_BNIN", "1") != "0"
 # workgroup per CU, or starting it only behind its stage's dgrad, lost more than the overlap gave.  Off by default also
 # because overlapping kernels make per-kernel timings unattributable (bench.py's roofline leg then reads 0.38 instead of
 # 0.49 for the dominant kernel).
+# One-channel head (the networks' configuration): the gradient of the head's input is dz * w[c] per pixel, so dec1's last stage
+# recomputes it in its BatchNorm-backward pass (unetdc_bn_relu_bwd_head) instead of reading a tensor the head backward wrote:
+# 2 x 268 MB less traffic per step at 8 x 512 x 512, bit-identical.  UNETDC_FUSE_HEAD_BWD=0: stored form (A/B).
+FUSE_HEAD_BWD = os.environ.get("UNETDC_FUSE_HEAD_BWD", "1") == "1"
+# First stage (enc1.0, one input channel): its weight gradient applies the stage's BatchNorm + ReLU backward on load
+# (unetdc_conv3x3_first_wgrad_bn) -- nothing else reads that stage's dy unless dL/dx is asked for, so the pass that writes it
+# (3 x 268 MB of traffic at 8 x 512 x 512) is not run.  Bit-identical.  UNETDC_FUSE_FIRST_BN=0: two-pass form (A/B).
+FUSE_FIRST_BN = os.environ.get("UNETDC_FUSE_FIRST_BN", "1") == "1"
 SIDE_WGRAD = os.environ.get("UNETDC_SIDE_WGRAD", "0") == "1"
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -499,7 +507,7 @@ class UNetEngine:
                 prev.mean.data_ptr(), prev.rstd.data_ptr(), prev.bwd_parts.data_ptr(), prev.bwd_parts.numel(),
                 __import__("ctypes").byref(self._np))
 
-    def _stage_bwd(self, st, flat, lvl, dskip, dpool, dx_out, fuse_prev=None, colsum=None, skip_for=None):
+    def _stage_bwd(self, st, flat, lvl, dskip, dpool, dx_out, fuse_prev=None, colsum=None, skip_for=None, head=None):
         """Backward of one stage.  dskip/dpool: incoming gradient(s) of the activation;
         dx_out: [npix, cin] view to receive the input gradient (None for the first stage);
         fuse_prev: the stage consuming dx_out as its activation gradient -- its BatchNorm-backward
@@ -521,6 +529,28 @@ class UNetEngine:
                  self._gview(flat, st.conv.bias).data_ptr(), ws, wsb, st.skip_parts.data_ptr(), st.skip_rows,
                  2 * st.cout, st.cout, N, h, w, st.cout, self.dt, s)
             st.skip_rows = 0
+        elif (st.first and FUSE_FIRST_BN and pre[0] is not None and dskip is not None and not self._frozen
+              and not getattr(self, "_need_dx", False) and self.side is None
+              and _lib.load().unetdc_conv3x3_first_wgrad_bn_supported(N, h, w, st.cin, st.cout, st.dil, self.dt)):
+            # BatchNorm backward of the first stage on load of its weight gradient: dy is never written
+            if getattr(st, "bwd_coeffs", None) is None:
+                st.bwd_coeffs = torch.empty(3 * st.cout, device=self.device, dtype=torch.float32)
+            call("unetdc_bn_relu_bwd_coeffs", pre[0], pre[1], st.bn.weight.data_ptr(), st.rstd.data_ptr(),
+                 self._gview(flat, st.bn.weight).data_ptr(), self._gview(flat, st.bn.bias).data_ptr(),
+                 self._gview(flat, st.conv.bias).data_ptr(), st.bwd_coeffs.data_ptr(), N, h, w, st.cout, s)
+            call("unetdc_conv3x3_first_wgrad_bn", st.x_in.data_ptr(), dskip.data_ptr(), dskip.stride(0), st.y.data_ptr(),
+                 st.y.stride(0), st.scale.data_ptr(), st.shift.data_ptr(), st.mean.data_ptr(), st.rstd.data_ptr(),
+                 st.bwd_coeffs.data_ptr(), self._gview(flat, st.conv.weight).data_ptr(), ws, wsb, N, h, w, st.cin, st.cout,
+                 st.dil, self.dt, s)
+            st.bwd_nparts = 0
+            return
+        elif head is not None:
+            # (dprobs, probs, head weight): the incoming gradient is recomputed per pixel, `dskip` was never written
+            call("unetdc_bn_relu_bwd_head", head[0].data_ptr(), head[1].data_ptr(), head[2].data_ptr(), st.y.data_ptr(),
+                 st.y.stride(0), st.scale.data_ptr(), st.shift.data_ptr(), st.mean.data_ptr(), st.rstd.data_ptr(),
+                 st.bn.weight.data_ptr(), dy.data_ptr(), dy.stride(0), self._gview(flat, st.bn.weight).data_ptr(),
+                 self._gview(flat, st.bn.bias).data_ptr(), self._gview(flat, st.conv.bias).data_ptr(), ws, wsb,
+                 pre[0], pre[1], N, h, w, st.cout, self.dt, s)
         else:
             self._bn_relu_bwd_plain(st, flat, dskip, dpool, dy, pre, ws, wsb, N, h, w, s)
         st.bwd_nparts = 0
@@ -587,11 +617,11 @@ class UNetEngine:
                 call("unetdc_conv3x3_dgrad", dy.data_ptr(), dy.stride(0), st.w_dgrad.data_ptr(), dx_out.data_ptr(),
                      dx_out.stride(0), N, h, w, st.cin, st.cout, st.dil, self.dt, s)
 
-    def _block_bwd(self, name, flat, lvl, dskip, dpool, dx_out, colsum=None, skip_for=None):
+    def _block_bwd(self, name, flat, lvl, dskip, dpool, dx_out, colsum=None, skip_for=None, head=None):
         """stage 3 then stage 0 of a block; the gradient between them lives in the 'da' buffer."""
         da = self.grad_bufs[("da", lvl)]
         s3, s0 = self.stages[(name, 3)], self.stages[(name, 0)]
-        self._stage_bwd(s3, flat, lvl, dskip, dpool, da, fuse_prev=s0)
+        self._stage_bwd(s3, flat, lvl, dskip, dpool, da, fuse_prev=s0, head=head)
         self._notify(flat, [s3.conv, s3.bn])             # per STAGE: bottleneck.3's 37.7 MB travel while bottleneck.0 computes
         self._stage_bwd(s0, flat, lvl, da, None, dx_out, colsum=colsum, skip_for=skip_for)
         self._notify(flat, [s0.conv, s0.bn])
@@ -616,9 +646,11 @@ class UNetEngine:
              self.H, self.W, self.cin, st.cout, st.dil, self.dt, _stream())
         return dx
 
-    def backward(self, dprobs, probs):
-        """dprobs, probs: [N, OC, H, W] fp32.  Returns the flat fp32 gradient buffer (parameters() order)."""
+    def backward(self, dprobs, probs, need_dx=False):
+        """dprobs, probs: [N, OC, H, W] fp32.  Returns the flat fp32 gradient buffer (parameters() order).
+        need_dx: input_grad() will be called afterwards (the first stage then keeps its dy)."""
         self._ensure_grad_bufs()
+        self._need_dx = bool(need_dx)
         s = _stream()
         N = self.N
         g = self.grad_bufs
@@ -628,9 +660,12 @@ class UNetEngine:
         oc = self.model.out_conv
         da = g[("da", 0)]
         last = self.stages[("dec1", 3)]                  # its activated output feeds out_conv
+        # one output channel, training statistics: the head's input gradient is never stored (see FUSE_HEAD_BWD)
+        head = (dprobs, probs, oc.weight) if (FUSE_BN_BWD and FUSE_HEAD_BWD and self.oc == 1 and not self._frozen) else None
         if FUSE_BN_BWD:                                  # da's BatchNorm-backward sums come out of the same pass
             call("unetdc_head_bwd_bnstats", dprobs.data_ptr(), probs.data_ptr(), _ptr(self.head_in),
-                 self.head_in.stride(0) if self.head_in is not None else 64, oc.weight.data_ptr(), da.data_ptr(), da.stride(0),
+                 self.head_in.stride(0) if self.head_in is not None else 64, oc.weight.data_ptr(),
+                 None if head is not None else da.data_ptr(), da.stride(0),
                  self._gview(flat, oc.weight).data_ptr(), self._gview(flat, oc.bias).data_ptr(), ws, wsb,
                  *self._bnstats_args(last), N, self.H, self.W, 64, self.oc, self.dt, s)
             last.bwd_nparts = self._np.value
@@ -649,7 +684,7 @@ class UNetEngine:
             dcat = g[("dcat", lvl)]
             # the dgrad that writes dcat = grad of cat([up, enc]) also sums its first half per channel = upconv bias grad
             self._block_bwd(f"dec{lvl}", flat, l, dact, None, dcat, colsum=(self._gview(flat, u["mod"].bias), 0, c),
-                            skip_for=(self.stages[(ENCODER[l], 3)], self.combo[lvl]))
+                            skip_for=(self.stages[(ENCODER[l], 3)], self.combo[lvl]), head=head if lvl == 1 else None)
             dup = dcat[:, :c]
             h, w = self.res[lvl]
             xin = u["x_in"]
@@ -709,7 +744,7 @@ class _UNetFunction(torch.autograd.Function):
                 "buffers per module, so run backward before the next forward (train or eval) of that module"
                 % (ctx.generation, eng.generation))
         x, probs = ctx.saved_tensors
-        flat = eng.backward(dprobs, probs)
+        flat = eng.backward(dprobs, probs, need_dx=ctx.needs_input_grad[0])
         finish = eng.model.grad_sync_finish
         if finish is not None:           # data parallel: wait (stream-side) for the bucket all-reduces
             finish()
