@@ -47,7 +47,8 @@ def test_operator_parity_under_switches(name):
 def test_train_step_under_unfused_switches_matches_default():
     """One bf16 training step at a small size: gradients with every fusion switched off, and with the opt-in split of the
     pooled stages' BatchNorm-backward sums (UNETDC_FUSE_POOL_SKIP=1), == the default path within bf16 rounding (same
-    kernels' math, different launch structure)."""
+    kernels' math, different launch structure); with only the round-3 backward fusions off (head-input gradient stored,
+    first stage's BatchNorm backward as its own pass) == the default path bit for bit."""
     code = r'''
 import sys, torch
 sys.path.insert(0, %r)
@@ -61,14 +62,19 @@ focal_dice_loss(m(x), t, alpha=1.0, gamma=2.0, ratio=0.3).backward()
 torch.save({k: p.grad.cpu() for k, p in m.named_parameters()}, sys.argv[1])
 ''' % ROOT
     outs = []
-    for i, extra in enumerate(({}, dict(SWITCH_SETS["unfused_epilogues"], UNETDC_FUSE_HEAD_BN="0"), {"UNETDC_FUSE_POOL_SKIP": "1"})):
+    arms = ({}, dict(SWITCH_SETS["unfused_epilogues"], UNETDC_FUSE_HEAD_BN="0"), {"UNETDC_FUSE_POOL_SKIP": "1"},
+            {"UNETDC_FUSE_HEAD_BWD": "0", "UNETDC_FUSE_FIRST_BN": "0"})
+    for i, extra in enumerate(arms):
         path = os.path.join("/tmp", f"unetdc_fallback_grads_{os.getpid()}_{i}.pt")
         r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **extra), cwd=ROOT,
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
         outs.append(torch.load(path, weights_only=True))
         os.remove(path)
-    for other in outs[1:]:
+    # stored head-input gradient + two-pass BatchNorm backward of the first stage: the fused forms are BIT-identical
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[3][k]), k
+    for other in outs[1:3]:
         for k in outs[0]:
             a, b = outs[0][k].double(), other[k].double()
             if k.endswith(".0.bias") or k.endswith(".3.bias"):
