@@ -101,6 +101,32 @@ template <> struct Chunk<bf16_t> {
   }
 };
 
+// element e (compile-time constant after unrolling) of a RAW 16-byte chunk, and its counterpart for building one: the
+// same conversions as Chunk<T>::unpack / pack, one element at a time (bf16 elements are packed in pairs: the even one is
+// parked in `prev` until the odd one arrives)
+template <typename T> __device__ __forceinline__ float chunk_elem(const u32x4& c, int e);
+template <> __device__ __forceinline__ float chunk_elem<float>(const u32x4& c, int e) {
+  const unsigned int u = c[e];
+  return bits_f32(u);
+}
+template <> __device__ __forceinline__ float chunk_elem<bf16_t>(const u32x4& c, int e) {
+  const unsigned int u = c[e >> 1];
+  return (e & 1) ? bits_f32(u & 0xffff0000u) : bits_f32(u << 16);
+}
+template <typename T> __device__ __forceinline__ void chunk_set(u32x4& c, int e, float v, float& prev);
+template <> __device__ __forceinline__ void chunk_set<float>(u32x4& c, int e, float v, float& prev) {
+  (void)prev;
+  c[e] = f32_bits(v);
+}
+template <> __device__ __forceinline__ void chunk_set<bf16_t>(u32x4& c, int e, float v, float& prev) {
+  if (e & 1) {
+    const bf16_t lo = (bf16_t)prev, hi = (bf16_t)v;
+    c[e >> 1] = (unsigned int)__builtin_bit_cast(unsigned short, lo) | ((unsigned int)__builtin_bit_cast(unsigned short, hi) << 16);
+  } else {
+    prev = v;
+  }
+}
+
 // two adjacent elements of T as one memory transaction, kept raw so that several can be in flight
 template <typename T> struct PairRaw;
 template <> struct PairRaw<bf16_t> {

@@ -280,42 +280,54 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdParams p) {
         }
         if (APPLY) st16(dyg + q * p.lddy + c0, Chunk<T>::pack(out));
       } else {
+        // The nine 16-byte chunks of a window (4 x y, 4 x dskip, dpool) stay RAW and every channel is taken out of them when
+        // its turn comes: holding them unpacked cost 160 / 192 registers (3 / 2 waves per SIMD on a pass that lives on
+        // memory-level parallelism).  Arithmetic and summation order per channel are unchanged.
         const int xq = (int)(q % Wq);
         const long t2 = q / Wq;
         const int yq = (int)(t2 % Hq), n = (int)(t2 / Hq);
-        float yv[4][EPC], dp[EPC];
         long pix[4];
+        u32x4 yr[4], sr[4], dpr, outr[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           pix[k] = ((long)n * p.H + 2 * yq + (k >> 1)) * p.W + 2 * xq + (k & 1);
-          Chunk<T>::unpack(ld16(yg + pix[k] * p.ldy + c0), yv[k]);
+          yr[k] = ld16(yg + pix[k] * p.ldy + c0);
         }
-        Chunk<T>::unpack(ld16(dpg + q * p.ldp + c0), dp);
-        int arg[EPC];
+        dpr = ld16(dpg + q * p.ldp + c0);
+        if (sg) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) sr[k] = ld16(sg + pix[k] * p.lds + c0);
+        }
+        float prev[4] = {0.f, 0.f, 0.f, 0.f};               // APPLY, bf16: the even element of a pair waits for the odd one
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
+          float yk[4], nrm[4];
           float best = 0.f;
-          arg[e] = 0;
+          int arg = 0;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const float a = round_through<T>(fmaxf(fmaf(yv[k][e], sc[e], sh[e]), 0.f));
-            if (k == 0 || a > best) { best = a; arg[e] = k; }
+            yk[k] = chunk_elem<T>(yr[k], e);
+            nrm[k] = fmaf(yk[k], sc[e], sh[e]);
+            const float a = round_through<T>(fmaxf(nrm[k], 0.f));
+            if (k == 0 || a > best) { best = a; arg = k; }
+          }
+          const float dpe = chunk_elem<T>(dpr, e);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float gin = (sg ? chunk_elem<T>(sr[k], e) : 0.f) + (arg == k ? dpe : 0.f);
+            const float gh = nrm[k] > 0.f ? gin : 0.f;
+            const float xh = (yk[k] - mu[e]) * rs[e];
+            if (APPLY) {
+              const float o = fmaf(k1[e], gh, -k2[e]) - k3[e] * xh;
+              chunk_set<T>(outr[k], e, o, prev[k]);
+            } else {
+              s1[e] += gh; s2[e] = fmaf(gh, xh, s2[e]); s3[e] += xh;
+            }
           }
         }
+        if (APPLY) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          float g[EPC], out[EPC];
-          if (sg) Chunk<T>::unpack(ld16(sg + pix[k] * p.lds + c0), g);
-#pragma unroll
-          for (int e = 0; e < EPC; ++e) {
-            const float gin = (sg ? g[e] : 0.f) + (arg[e] == k ? dp[e] : 0.f);
-            const float nrm = fmaf(yv[k][e], sc[e], sh[e]);
-            const float gh = nrm > 0.f ? gin : 0.f;
-            const float xh = (yv[k][e] - mu[e]) * rs[e];
-            if (APPLY) out[e] = fmaf(k1[e], gh, -k2[e]) - k3[e] * xh;
-            else { s1[e] += gh; s2[e] = fmaf(gh, xh, s2[e]); s3[e] += xh; }
-          }
-          if (APPLY) st16(dyg + pix[k] * p.lddy + c0, Chunk<T>::pack(out));
+          for (int k = 0; k < 4; ++k) st16(dyg + pix[k] * p.lddy + c0, outr[k]);
         }
       }
     }
@@ -465,8 +477,12 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadParams p) {
 
 // dz = dp * p * (1-p);  dA[pix][c] = sum_oc dz[oc]*w[oc][c];  partial sums of dz*a (dW) and dz (db)
 // parts layout: [gridDim.x][OC][C + 1]   (last column = bias gradient)
-template <typename T, bool BN>
+// LEAN (the training path of the networks: one output channel, activation recomputed from y, input gradient not stored): the
+// saved output stays a RAW chunk and each channel is taken out of it in turn -- 158 -> fewer registers, i.e. every workgroup of
+// the 1024 resident at once instead of three quarters of them.  Same arithmetic, same order.
+template <typename T, bool BN, bool LEAN = false>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadParams p) {
+  static_assert(!LEAN || BN, "lean form: fused BatchNorm-backward sums");
   constexpr int EPC = Chunk<T>::N;
   __shared__ float red[256 * (EPC + 1)];
   __shared__ float red3[BN ? 256 * 3 * EPC : 1];
@@ -496,6 +512,40 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const HeadParams p) {
     // two pixels per lane group and trip: every load of both is issued before the arithmetic of the first (one 16-byte load
     // in flight per lane at 3 waves per SIMD left the kernel latency bound at 3.4 TB/s)
     constexpr int U = 2;
+    if (LEAN) {
+      for (long pb = (long)blockIdx.x * ppb * U; pb < P; pb += (long)gridDim.x * ppb * U) {
+        u32x4 yraw[U];
+        float pr[U], dpv[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const long px0 = pb + u * ppb + pl;
+          ok[u] = px0 < P;
+          const long px = ok[u] ? px0 : 0;
+          pr[u] = p.probs[px];                             // OC == 1: [N, 1, H, W] is the pixel index itself
+          dpv[u] = p.dprobs[px];
+          yraw[u] = ld16(yg + px * p.bn_ldy + cl * EPC);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (!ok[u]) continue;
+          float dz = dpv[u] * pr[u] * (1.f - pr[u]);
+          asm volatile("" : "+v"(dz));                     // a rounded product, as in the stored form: no contraction into `gb += dz`
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            const float yv = chunk_elem<T>(yraw[u], e);
+            const float nrm = fmaf(yv, sc[e], sh[e]);
+            const float av = round_through<T>(fmaxf(nrm, 0.f));
+            gw[e] = fmaf(dz, av, gw[e]);
+            const float g = round_through<T>(0.f + dz * wv[e]);
+            const float gh = nrm > 0.f ? g : 0.f;
+            const float xh = (yv - mu[e]) * rs[e];
+            s1[e] += gh; s2[e] = fmaf(gh, xh, s2[e]); s3[e] += xh;
+          }
+          if (cl == 0) gb += dz;
+        }
+      }
+    } else
     for (long pb = (long)blockIdx.x * ppb * U; pb < P; pb += (long)gridDim.x * ppb * U) {
       long pix[U];
       bool ok[U];
@@ -1065,11 +1115,14 @@ int launch_head_bwd(HeadParams& p, float* dw, float* db, void* workspace, long w
     return UNETDC_EWORKSPACE;
   }
   p.parts = reinterpret_cast<float*>(workspace);
+  const bool lean = bn && !p.a && !p.da && p.OC == 1;
   if (dtype == UNETDC_BF16) {
-    if (bn) hipLaunchKernelGGL((head_bwd_kernel<bf16_t, true>), dim3(nb), dim3(256), 0, stream, p);
+    if (lean) hipLaunchKernelGGL((head_bwd_kernel<bf16_t, true, true>), dim3(nb), dim3(256), 0, stream, p);
+    else if (bn) hipLaunchKernelGGL((head_bwd_kernel<bf16_t, true>), dim3(nb), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((head_bwd_kernel<bf16_t, false>), dim3(nb), dim3(256), 0, stream, p);
   } else {
-    if (bn) hipLaunchKernelGGL((head_bwd_kernel<float, true>), dim3(nb), dim3(256), 0, stream, p);
+    if (lean) hipLaunchKernelGGL((head_bwd_kernel<float, true, true>), dim3(nb), dim3(256), 0, stream, p);
+    else if (bn) hipLaunchKernelGGL((head_bwd_kernel<float, true>), dim3(nb), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((head_bwd_kernel<float, false>), dim3(nb), dim3(256), 0, stream, p);
   }
   rc = check_launch("head_bwd_kernel");
