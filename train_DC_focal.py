@@ -117,8 +117,13 @@ def main(argv=None, parser=None):
     history = []
     for epoch in range(args.epochs):
         model.train()
-        tr_loss = tr_dice = 0.0
-        correct = total = 0
+        # the per-step metrics of train_DC_focal.py:256-262 are ACCUMULATED ON THE DEVICE (fp64 / int64: the same values added in
+        # the same order as the reference's Python floats) and read back once per epoch: three .item() calls per step would
+        # stall the launch queue three times per step
+        tr_loss_t = torch.zeros((), dtype=torch.float64, device=device)
+        tr_dice_t = torch.zeros((), dtype=torch.float64, device=device)
+        correct_t = torch.zeros((), dtype=torch.int64, device=device)
+        total = 0
         t0, seen = time.time(), 0
         for step, batch in enumerate(train_loader):
             if args.steps and step >= args.steps:
@@ -131,29 +136,34 @@ def main(argv=None, parser=None):
             if wrapper is not None and not images.is_cuda:
                 wrapper.sync_gradients()                    # ATen-CPU path: explicit all-reduce
             optimizer.step()
-            tr_loss += loss.item()
-            pred = (outputs > 0.3).float()
-            tr_dice += dice_coef(masks, pred).item()
-            correct += int((pred == masks).sum().item())
+            with torch.no_grad():
+                tr_loss_t += loss.detach().double()
+                pred = (outputs > 0.3).float()
+                tr_dice_t += dice_coef(masks, pred).double()
+                correct_t += (pred == masks).sum()
             total += masks.numel()
             seen += images.shape[0]
         nb = max(1, min(len(train_loader), args.steps or len(train_loader)))
+        tr_loss, tr_dice, correct = float(tr_loss_t.item()), float(tr_dice_t.item()), int(correct_t.item())   # (waits for the epoch's work)
         dt = time.time() - t0
         # -------- validation --------
         if wrapper is not None:
             wrapper.broadcast_buffers()                     # rank 0's BatchNorm running statistics everywhere
         model.eval()
-        va_loss = va_dice = 0.0
-        vc = vt = 0
+        va_loss_t = torch.zeros((), dtype=torch.float64, device=device)
+        va_dice_t = torch.zeros((), dtype=torch.float64, device=device)
+        vc_t = torch.zeros((), dtype=torch.int64, device=device)
+        vt = 0
         with torch.no_grad():
             for batch in val_loader:
                 images, masks = batch[0].float().to(device), batch[1].float().to(device)
                 outputs = model(images)
-                va_loss += criterion(outputs, masks).item()
+                va_loss_t += criterion(outputs, masks).double()
                 pred = (outputs > 0.3).float()
-                va_dice += dice_coef(masks, pred).item()
-                vc += int((pred == masks).sum().item())
+                va_dice_t += dice_coef(masks, pred).double()
+                vc_t += (pred == masks).sum()
                 vt += masks.numel()
+        va_loss, va_dice, vc = float(va_loss_t.item()), float(va_dice_t.item()), int(vc_t.item())
         nv = max(1, len(val_loader))
         rec = dict(epoch=epoch + 1, train_loss=tr_loss / nb, val_loss=va_loss / nv, train_dice=tr_dice / nb,
                    val_dice=va_dice / nv, train_acc=correct / max(total, 1), val_acc=vc / max(vt, 1),
