@@ -106,9 +106,12 @@ def main(argv=None, parser=None):
         per_rank = len(train_ds) // world
         train_ds = Subset(train_ds, list(range(rank, per_rank * world, world)))
     pin = device.type == "cuda"
+    # worker processes live across epochs (re-spawning them costs seconds per epoch: an interpreter + torch import each)
+    keep = args.workers > 0
     train_loader = DataLoader(train_ds, batch_size=args.batch, shuffle=True, num_workers=args.workers,
-                              pin_memory=pin, drop_last=True)
-    val_loader = DataLoader(val_ds, batch_size=args.batch, shuffle=False, num_workers=args.workers, pin_memory=pin)
+                              pin_memory=pin, drop_last=True, persistent_workers=keep)
+    val_loader = DataLoader(val_ds, batch_size=args.batch, shuffle=False, num_workers=args.workers, pin_memory=pin,
+                            persistent_workers=keep)
     if rank == 0:
         print(f"Training set: {len(train_ds)} images/rank, validation set: {len(val_ds)} images, "
               f"{world} rank(s), device {device}, compute {args.dtype}")
