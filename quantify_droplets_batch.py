@@ -39,8 +39,13 @@ def load_model(ckpt, dtype="f32"):
     return m.to(DEVICE).eval()
 
 
-def preprocess(path, background_radius):
-    im = np.array(Image.open(path).convert("RGB"))
+def decode_rgb(path):
+    """File -> uint8 RGB array (runs in the decode pool: PIL releases the GIL while it inflates)."""
+    return np.array(Image.open(path).convert("RGB"))
+
+
+def preprocess(path, background_radius, im=None):
+    im = decode_rgb(path) if im is None else im
     oh, ow = im.shape[:2]
     if DEVICE == "cuda":                                 # rolling ball + resize + /255 + CHW on the GPU (csrc/preprocess.hip)
         from unet_dc_segmentation_amd.preprocess import preprocess_device
@@ -94,8 +99,18 @@ def _outline(mask):
     return mask.astype(bool) & ~ndimage.binary_erosion(mask.astype(bool), iterations=2)
 
 
+def _write_outputs(mask, df, fpath, name, mask_dir, overlay_dir):
+    """The per-image files of run_batch (reference :66-79): mask PNG, droplet CSV, optional overlay."""
+    Image.fromarray(mask * 255).save(str(mask_dir / f"{name}_pred.png"))
+    df.to_csv(mask_dir.parent / f"{name}_droplets.csv", index=False)
+    if overlay_dir is not None:
+        img = np.array(Image.open(fpath).convert("RGB"))
+        img[_outline(mask)] = (0, 255, 0)
+        Image.fromarray(img).save(str(overlay_dir / f"{name}_overlay.png"))
+
+
 @torch.no_grad()
-def run_batch(tensors, meta, model, mask_dir, overlay_dir, thresh, min_area, px_per_um, per_image_rows, all_props):
+def run_batch(tensors, meta, model, mask_dir, overlay_dir, thresh, min_area, px_per_um, per_image_rows, all_props, writers=None):
     batch = torch.stack(tensors).to(DEVICE)
     probs = model(batch)                                 # sigmoid probabilities (model_2.py:80)
     on_device = probs.is_cuda
@@ -112,16 +127,16 @@ def run_batch(tensors, meta, model, mask_dir, overlay_dir, thresh, min_area, px_
         else:
             mask = resize_mask_like_reference(masks512[i], ow, oh)
             df = quantify(mask, min_area, px_per_um)
-        Image.fromarray(mask * 255).save(str(mask_dir / f"{name}_pred.png"))
         df.insert(0, "filename", Path(fpath).name) if not df.empty else None
-        df.to_csv(mask_dir.parent / f"{name}_droplets.csv", index=False)
         all_props.append(df)
         per_image_rows.append({"filename": Path(fpath).name, "droplet_count": len(df),
                                "total_area_px": df["area"].sum() if not df.empty else 0})
-        if overlay_dir is not None:
-            img = np.array(Image.open(fpath).convert("RGB"))
-            img[_outline(mask)] = (0, 255, 0)
-            Image.fromarray(img).save(str(overlay_dir / f"{name}_overlay.png"))
+        # PNG deflate and CSV formatting are the slowest part of an image once the network runs on the device: they go to
+        # the writer pool (same files, same contents; main() waits for them before the summary is written)
+        if writers is None:
+            _write_outputs(mask, df, fpath, name, mask_dir, overlay_dir)
+        else:
+            writers[1].append(writers[0].submit(_write_outputs, mask, df, fpath, name, mask_dir, overlay_dir))
 
 
 def build_parser():
@@ -153,17 +168,40 @@ def main(argv=None):
     model = load_model(args.ckpt_path, args.dtype)
     tensors, meta, per_image_rows, all_props = [], [], [], []
     images = sorted(p for p in in_dir.iterdir() if p.suffix.lower() in {".png", ".jpg", ".jpeg", ".tif", ".tiff"})
-    for img in images:
-        t, osize = preprocess(img, args.background_radius)
-        tensors.append(t)
-        meta.append((str(img), osize))
-        if len(tensors) == args.batch:
+    # File decode runs ahead of the device and the per-image writes behind it, in two small thread pools (both are
+    # zlib-bound and release the GIL); the order of the rows in the summary files is the order of `images` as before.
+    import os
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    nthreads = max(1, min(8, (os.cpu_count() or 2) // 2))
+    with ThreadPoolExecutor(nthreads) as dec_pool, ThreadPoolExecutor(nthreads) as wr_pool:
+        writers = (wr_pool, [])
+        ahead = deque()
+        it = iter(images)
+
+        def refill():
+            while len(ahead) < 2 * args.batch:
+                nxt = next(it, None)
+                if nxt is None:
+                    return
+                ahead.append((nxt, dec_pool.submit(decode_rgb, nxt)))
+
+        refill()
+        while ahead:
+            img, fut = ahead.popleft()
+            refill()
+            t, osize = preprocess(img, args.background_radius, fut.result())
+            tensors.append(t)
+            meta.append((str(img), osize))
+            if len(tensors) == args.batch:
+                run_batch(tensors, meta, model, mask_dir, overlay_dir, args.prob_thresh, args.min_area,
+                          args.px_per_micron, per_image_rows, all_props, writers)
+                tensors, meta = [], []
+        if tensors:
             run_batch(tensors, meta, model, mask_dir, overlay_dir, args.prob_thresh, args.min_area,
-                      args.px_per_micron, per_image_rows, all_props)
-            tensors, meta = [], []
-    if tensors:
-        run_batch(tensors, meta, model, mask_dir, overlay_dir, args.prob_thresh, args.min_area,
-                  args.px_per_micron, per_image_rows, all_props)
+                      args.px_per_micron, per_image_rows, all_props, writers)
+        for f in writers[1]:
+            f.result()                                   # re-raises a failed write
     summary_df = pd.DataFrame(per_image_rows)
     summary_df.to_csv(out_dir / "summary_per_image.csv", index=False)
     props = [d for d in all_props if not d.empty]
