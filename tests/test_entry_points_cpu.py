@@ -91,6 +91,26 @@ def test_train_entry_point_cpu(tmp_path):
     if ckpt.exists():
         sd = torch.load(ckpt, weights_only=True)
         assert len(sd) == 136
+        # final test evaluation of the best checkpoint on the held-out split (reference train_DC_focal.py:365-402, :452-467)
+        tr = hist.test
+        assert tr is not None and np.isfinite(tr["test_loss"]) and 0.0 <= tr["test_dice"] <= 1.0 and 0.0 <= tr["test_acc"] <= 1.0
+        cm = np.asarray(tr["confusion"])
+        assert cm.shape == (2, 2) and cm.sum() == 2 * 32 * 32            # 10 tiles: 6 train / 2 val / 2 test
+        assert abs(tr["test_acc"] - (cm[0, 0] + cm[1, 1]) / cm.sum()) < 1e-12
+
+
+def test_train_entry_point_keeps_the_ragged_last_training_batch(tmp_path, monkeypatch):
+    """The reference's train loader has no drop_last (train_DC_focal.py:200): with 7 training tiles at batch 2 the epoch has
+    FOUR steps and the last one sees a single tile."""
+    import train_DC_focal as t
+    seen = []
+    orig = t.focal_dice_loss
+    monkeypatch.setattr(t, "focal_dice_loss", lambda pred, tgt, **kw: (seen.append(pred.shape[0]), orig(pred, tgt, **kw))[1])
+    hist = t.main(["--synthetic", "--synthetic_len", "11", "--img_size", "32", "--batch", "2", "--epochs", "1",
+                   "--workers", "0", "--in_channels", "1", "--device", "cpu", "--ckpt_path", str(tmp_path / "b.pth"),
+                   "--no_test_eval"])
+    assert hist.test is None
+    assert seen[:4] == [2, 2, 2, 1], seen                               # 11 tiles: 2 test, 2 validation, 7 training
 
 
 def test_hip_path_fails_loudly_without_library(monkeypatch, tmp_path):
@@ -103,11 +123,11 @@ def test_hip_path_fails_loudly_without_library(monkeypatch, tmp_path):
         _lib.load()
 
 
-def test_calculate_metrics_matches_sklearn_and_plot(tmp_path):
+def test_calculate_metrics_matches_sklearn():
     """Five return values like the reference (utils/metrics_DC.py:75-85, which calls sklearn): checked against
     sklearn itself, including the all-negative corner (zero_division=1)."""
     from sklearn.metrics import confusion_matrix, f1_score, precision_score, recall_score
-    from utils.metrics_DC import calculate_metrics, plot_binary_confusion_matrix_with_metrics
+    from utils.metrics_DC import calculate_metrics
     g = torch.Generator().manual_seed(3)
     for yt, yp in [((torch.rand(2, 1, 16, 16, generator=g) < 0.3).float(), torch.rand(2, 1, 16, 16, generator=g)),
                    (torch.zeros(1, 1, 8, 8), torch.rand(1, 1, 8, 8, generator=g) * 0.2)]:
@@ -120,8 +140,6 @@ def test_calculate_metrics_matches_sklearn_and_plot(tmp_path):
         assert np.array_equal(cm, ref) and cm.shape == (2, 2)
         tn, fp = ref[0]
         assert abs(sp - (tn / (tn + fp) if tn + fp else 0)) < 1e-12
-    out = plot_binary_confusion_matrix_with_metrics(cm, 0.9, path=str(tmp_path / "cm.png"))
-    assert os.path.getsize(out) > 1000
 
 
 def test_dataset_transform_conventions_and_worker_seeding(tmp_path):

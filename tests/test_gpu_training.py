@@ -88,8 +88,9 @@ def test_thirty_training_steps_bf16_tracks_fp32_and_cpu_reference():
 
 
 def test_train_entry_point_on_device_partial_validation_batch_and_checkpoint(tmp_path, monkeypatch):
-    """train_DC_focal.main() on the HIP device (bf16 compute, FusedAdam): 2 epochs of 3 steps, a validation set of 5 tiles
-    at batch 4 (last batch ragged: exercises the per-shape engine cache), best checkpoint written and read back through
+    """train_DC_focal.main() on the HIP device (bf16 compute, FusedAdam): 2 epochs over 17 training tiles at batch 4 (the last
+    training batch is a single tile, as in the reference whose loader has no drop_last), a validation and a test set of 5 tiles
+    (last batches ragged: exercises the per-shape engine cache), the final test evaluation, best checkpoint written and read back through
     quantify_droplets_batch.load_model, whose eval forward must match the CPU oracle on the saved weights."""
     import quantify_droplets_batch as q
     import train_DC_focal as t
@@ -104,10 +105,11 @@ def test_train_entry_point_on_device_partial_validation_batch_and_checkpoint(tmp
     monkeypatch.setattr(engine.UNetEngine, "__init__", counting)
     ckpt = tmp_path / "best.pth"
     torch.cuda.reset_peak_memory_stats()
-    hist = t.main(["--synthetic", "--synthetic_len", "26", "--img_size", "64", "--batch", "4", "--epochs", "2", "--steps", "3",
+    hist = t.main(["--synthetic", "--synthetic_len", "27", "--img_size", "64", "--batch", "4", "--epochs", "2",
                    "--workers", "0", "--in_channels", "3", "--dtype", "bf16", "--device", "cuda", "--patience", "5",
                    "--ckpt_path", str(ckpt)])
     assert len(hist) == 2 and all(np.isfinite(h["train_loss"]) and np.isfinite(h["val_loss"]) for h in hist)
+    assert hist.test is not None and np.isfinite(hist.test["test_loss"]) and np.asarray(hist.test["confusion"]).sum() == 5 * 64 * 64
     # engines: the training shape (also the full validation batches) and the ragged validation batch -- built ONCE each,
     # not once per epoch
     assert sorted(built) == [(1, 3, 64, 64), (4, 3, 64, 64)], built

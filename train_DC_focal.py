@@ -8,8 +8,9 @@ to ``best_UNetDC_focal_model.pth``) behind argparse flags whose defaults are tho
 New: ``--synthetic`` (seeded droplet tiles, no dataset needed), ``--dtype`` (f32 | bf16 compute on
 the HIP path), ``--steps`` (cap the steps per epoch), and data-parallel training when launched with
 ``python -m torch.distributed.run --nproc-per-node N train_DC_focal.py ...`` (RCCL all-reduce
-overlapped with backward, unet_dc_segmentation_amd/dp.py).  PNG dumps / plots of the reference's
-test section (:365-611) are visualisation and out of scope.
+overlapped with backward, unet_dc_segmentation_amd/dp.py).  The numbers of the reference's test section (:365-402, :452-467:
+best checkpoint reloaded, test loss / Dice / pixel accuracy, precision / recall / F1 / specificity / confusion matrix) are
+computed and printed; its PNG dumps and plots (:404-450, :468-611) are visualisation and out of scope.
 """
 import argparse
 import os
@@ -20,7 +21,7 @@ from torch.utils.data import DataLoader, Subset
 
 from unet_dc_segmentation_amd import dp as dpmod
 from utils.data_loader import SegmentationDataset, SyntheticDropletDataset, TrainAugment
-from utils.metrics_DC import combined_loss, dice_coef, focal_dice_loss
+from utils.metrics_DC import calculate_metrics, combined_loss, dice_coef, focal_dice_loss
 
 
 def build_parser(arch="unetdc", epochs=15, ckpt="best_UNetDC_focal_model.pth", loss="focal_dice"):
@@ -44,6 +45,8 @@ def build_parser(arch="unetdc", epochs=15, ckpt="best_UNetDC_focal_model.pth", l
     p.add_argument("--workers", type=int, default=4)
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--ckpt_path", default=ckpt)
+    p.add_argument("--no_test_eval", dest="test_eval", action="store_false",
+                   help="skip the evaluation of the best checkpoint on the held-out test split after training")
     p.add_argument("--device", default="cuda" if torch.cuda.is_available() else "cpu")
     return p
 
@@ -72,6 +75,39 @@ def make_datasets(args):
     return mk(tr, TrainAugment(args.seed)), mk(va, None), mk(te, None)
 
 
+class History(list):
+    """Per-epoch records of main(); ``.test`` holds the held-out-split results of the final evaluation (None if skipped)."""
+    test = None
+
+
+def evaluate_test(model, loader, criterion, device):
+    """The reference's final test pass (train_DC_focal.py:365-402, :452-467) without its image dumps: mean loss and Dice over
+    the batches, pixel accuracy over all pixels, and calculate_metrics() on the thresholded predictions.  Sums stay on the
+    device (one read-back), like the training loop's."""
+    model.eval()
+    loss_t = torch.zeros((), dtype=torch.float64, device=device)
+    dice_t = torch.zeros((), dtype=torch.float64, device=device)
+    cm_t = torch.zeros(4, dtype=torch.int64, device=device)           # tn, fp, fn, tp
+    with torch.no_grad():
+        for batch in loader:
+            images, masks = batch[0].float().to(device), batch[1].float().to(device)
+            outputs = model(images)
+            loss_t += criterion(outputs, masks).double()
+            pred = (outputs > 0.3).float()
+            dice_t += dice_coef(masks, pred).double()
+            yt, yp = masks > 0.5, pred > 0.5
+            cm_t += torch.stack([(~yp & ~yt).sum(), (yp & ~yt).sum(), (~yp & yt).sum(), (yp & yt).sum()])
+    nb = max(1, len(loader))
+    tn, fp, fn, tp = (int(v) for v in cm_t.tolist())
+    # calculate_metrics() takes label tensors; four run-length blocks reproduce the confusion matrix without moving the masks
+    y_true = torch.cat([torch.zeros(tn + fp), torch.ones(fn + tp)])
+    y_pred = torch.cat([torch.zeros(tn), torch.ones(fp), torch.zeros(fn), torch.ones(tp)])
+    precision, recall, f1, specificity, cm = calculate_metrics(y_true, y_pred)
+    total = max(1, tn + fp + fn + tp)
+    return dict(test_loss=float(loss_t.item()) / nb, test_dice=float(dice_t.item()) / nb, test_acc=(tn + tp) / total,
+                precision=precision, recall=recall, f1=f1, specificity=specificity, confusion=cm.tolist())
+
+
 def main(argv=None, parser=None):
     args = (parser or build_parser()).parse_args(argv)
     rank, local, world = dpmod.init_from_env()
@@ -98,7 +134,7 @@ def main(argv=None, parser=None):
     else:
         optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, fused=next(model.parameters()).is_cuda)
 
-    train_ds, val_ds, _ = make_datasets(args)
+    train_ds, val_ds, test_ds = make_datasets(args)
     if world > 1:
         # each rank draws its own shard; shards are truncated to EQUAL length (as DistributedSampler with
         # drop_last does) so that every rank runs the same number of steps -- an extra step on one rank would
@@ -108,8 +144,10 @@ def main(argv=None, parser=None):
     pin = device.type == "cuda"
     # worker processes live across epochs (re-spawning them costs seconds per epoch: an interpreter + torch import each)
     keep = args.workers > 0
+    # no drop_last, like the reference's loader (train_DC_focal.py:200): the ragged last batch trains too (the engines of both
+    # batch shapes stay alive, unet.py::_engine_for; under data parallelism the shards are equal, so is every rank's last batch)
     train_loader = DataLoader(train_ds, batch_size=args.batch, shuffle=True, num_workers=args.workers,
-                              pin_memory=pin, drop_last=True, persistent_workers=keep)
+                              pin_memory=pin, persistent_workers=keep)
     val_loader = DataLoader(val_ds, batch_size=args.batch, shuffle=False, num_workers=args.workers, pin_memory=pin,
                             persistent_workers=keep)
     if rank == 0:
@@ -117,7 +155,7 @@ def main(argv=None, parser=None):
               f"{world} rank(s), device {device}, compute {args.dtype}")
 
     best_dice, patience_counter = 0.0, 0
-    history = []
+    history = History()
     for epoch in range(args.epochs):
         model.train()
         # the per-step metrics of train_DC_focal.py:256-262 are ACCUMULATED ON THE DEVICE (fp64 / int64: the same values added in
@@ -195,6 +233,22 @@ def main(argv=None, parser=None):
             if rank == 0:
                 print("Early stopping!")
             break
+    # -------- final test evaluation (train_DC_focal.py:365-402, :452-467): best checkpoint, held-out split --------
+    if world > 1:
+        torch.distributed.barrier()                         # rank 0 has finished writing the checkpoint
+    if args.test_eval and os.path.exists(args.ckpt_path) and len(test_ds) > 0:
+        model.load_state_dict(torch.load(args.ckpt_path, map_location=device, weights_only=True))
+        test_loader = DataLoader(test_ds, batch_size=args.batch, shuffle=False, num_workers=args.workers, pin_memory=pin)
+        history.test = evaluate_test(model, test_loader, criterion, device)       # every rank: same weights, same split
+        if rank == 0:
+            t = history.test
+            print("========== Test Results ==========")
+            print(f"Test Loss: {t['test_loss']:.4f}")
+            print(f"Test Dice: {t['test_dice']:.4f}")
+            print(f"Test Accuracy (pixel-wise): {t['test_acc']:.4f}")
+            print(f"Precision: {t['precision']:.4f}, Recall: {t['recall']:.4f}, F1: {t['f1']:.4f}, "
+                  f"Specificity: {t['specificity']:.4f}")
+            print(f"Confusion matrix [[tn, fp], [fn, tp]]: {t['confusion']}")
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

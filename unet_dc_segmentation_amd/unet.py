@@ -73,12 +73,12 @@ class _UNetFamily(nn.Module):
         self._engines, self._weights = {}, None
         return self
 
-    MAX_ENGINES = 3
+    MAX_ENGINES = 4      # train_DC_focal.py: full batch, ragged last training batch, ragged last validation batch, ragged test batch
 
     def _engine_for(self, x):
-        """One engine (activation buffers, schedule) per input shape, a few kept alive: the ragged last validation batch of
-        train_DC_focal.py (its val_loader has no drop_last) must not free and re-allocate the training-shape buffers every
-        epoch.  The packed weight images are shared (engine.PackedWeights)."""
+        """One engine (activation buffers, schedule) per input shape, a few kept alive: the ragged last training and validation
+        batches of train_DC_focal.py (its loaders have no drop_last, like the reference's) must not free and re-allocate the
+        full-batch buffers every epoch.  The packed weight images are shared (engine.PackedWeights)."""
         from . import engine                           # raises if libunetdc_hip.so is missing
         key = (x.device, tuple(x.shape))
         eng = self._engines.pop(key, None)

@@ -5,8 +5,8 @@ The autograd of :func:`focal_dice_loss` produces dL/dprobs, which is the input o
 backward pass (head backward kernel).  Reference lines: dice_loss :11-17, combined_loss :19-22,
 dice_coef :24-29, FocalLoss :31-63, focal_dice_loss :65-73, calculate_metrics :75-85.
 calculate_metrics returns the reference's five values (precision, recall, F1, specificity, 2x2 confusion
-matrix laid out like sklearn's: [[tn, fp], [fn, tp]]); plot_binary_confusion_matrix_with_metrics (:87-116) draws
-the same annotated heat map with matplotlib alone (seaborn is not a dependency here).
+matrix laid out like sklearn's: [[tn, fp], [fn, tp]]) and is what train_DC_focal.py's final test evaluation prints; the
+reference's confusion-matrix PLOT (:87-116) is reporting, out of scope.
 """
 from __future__ import annotations
 
@@ -88,30 +88,3 @@ def calculate_metrics(y_true, y_pred):
     specificity = tn / (tn + fp) if tn + fp > 0 else 0
     conf_matrix = np.array([[tn, fp], [fn, tp]], dtype=np.int64)
     return precision, recall, f1, specificity, conf_matrix
-
-
-def plot_binary_confusion_matrix_with_metrics(cm, accuracy, path="confusion_matrix_.png"):
-    """2x2 confusion matrix with per-class precision / recall / specificity on the diagonal and the overall
-    accuracy in the title, saved to ``confusion_matrix_.png`` (reference :87-116; matplotlib only)."""
-    import matplotlib
-    matplotlib.use("Agg")
-    import matplotlib.pyplot as plt
-    tn, fp, fn, tp = (int(v) for v in np.asarray(cm).ravel())
-    ratio = lambda a, b: a / b if b > 0 else 0                                  # noqa: E731
-    annot = [[f"{tn}\nPr={ratio(tn, tn + fn):.2f}\nRec={ratio(tn, tn + fp):.2f}\nSp={ratio(tp, tp + fp):.2f}", f"{fp}"],
-             [f"{fn}", f"{tp}\nPr={ratio(tp, tp + fp):.2f}\nRec={ratio(tp, tp + fn):.2f}\nSp={ratio(tn, tn + fn):.2f}"]]
-    fig, ax = plt.subplots(figsize=(6, 5))
-    im = ax.imshow(np.asarray(cm, dtype=float), cmap="Blues")
-    fig.colorbar(im, ax=ax)
-    ax.set_xticks([0, 1], labels=["Negative", "Positive"])
-    ax.set_yticks([0, 1], labels=["Negative", "Positive"])
-    for i in range(2):
-        for j in range(2):
-            ax.text(j, i, annot[i][j], ha="center", va="center")
-    ax.set_title(f"Overall Accuracy: {accuracy:.3f}")
-    ax.set_xlabel("Predicted")
-    ax.set_ylabel("Actual")
-    fig.tight_layout()
-    fig.savefig(path)
-    plt.close(fig)
-    return path
