@@ -38,6 +38,10 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+# empirical ceilings measured on MI355X (MI355X_MICROARCH.md): float4 copy 6.29 TB/s; the best plain 256 x 256 bf16 GEMM on random
+# data 1.32-1.47 PFLOP/s (the chip lowers its clock under MFMA load: "DVFS give-back").  Reported NEXT to the datasheet fractions.
+EMPIRICAL_HBM_GBS = 6290.0
+EMPIRICAL_BF16_TFLOPS = 1470.0
 
 
 def synthetic_batch(seed, n, h, w, cin=1, discs=200):
@@ -90,7 +94,7 @@ def pmc_traffic(kernel):
     """Per-launch bytes past the L2 for `kernel` from the committed rocprofv3 PMC summary (separate FETCH_SIZE /
     WRITE_SIZE passes, gfx950 x2 correction on the read side; tools/pmc_traffic.sh), or None -- also None when the
     summary was measured on different kernel sources than the ones built here (source-hash stamp)."""
-    for tag in ("r03", "r02", "r01"):
+    for tag in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
         try:
             doc = json.load(open(path))
@@ -312,7 +316,9 @@ def hbm_leg(step, es, nsteps=3):
                      "algorithmic_GB_per_step": nbytes / nsteps / 1e9, "achieved_GBps": gbs, "frac": gbs / PEAK_HBM_GBS})
     tot_b, tot_ms = sum(v[0] for v in agg.values()), sum(v[1] for v in agg.values())
     return {"bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s", "achieved": tot_b / (tot_ms * 1e-3) / 1e9 if tot_ms else None,
-            "frac": tot_b / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if tot_ms else None, "ms_per_step": tot_ms / nsteps,
+            "frac": tot_b / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if tot_ms else None,
+            "empirical_peak": EMPIRICAL_HBM_GBS, "frac_of_empirical": tot_b / (tot_ms * 1e-3) / 1e9 / EMPIRICAL_HBM_GBS if tot_ms else None,
+            "ms_per_step": tot_ms / nsteps,
             "measured": f"HIP events around each call, {nsteps} instrumented steps after the timed region", "entries": rows}
 
 
@@ -444,7 +450,7 @@ def self_launch(args, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--size", type=int, default=512)
@@ -541,9 +547,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     _lib.start_timing(igemm_calls)
+    # per-step device time: one HIP event per step boundary on the launch stream (recording does not synchronise)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -554,6 +564,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     final_loss = float(loss.item())
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    pct = lambda q: step_ms[min(len(step_ms) - 1, max(0, int(round(q * (len(step_ms) - 1)))))]   # noqa: E731
+    step_stats = {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "min": step_ms[0], "max": step_ms[-1], "n": len(step_ms),
+                  "measured": "HIP events on the launch stream at the step boundaries of the timed region (rank 0)"}
     hbm = hbm_leg(step, 2 if args.dtype == "bf16" else 4) if args.mode == "train" else None
 
     if rank == 0:
@@ -579,6 +593,8 @@ def main():
         dom = kernels[0]
         roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak,
                     "unit": "TFLOP/s", "frac": dom["tflops"] / peak,
+                    "empirical_peak": EMPIRICAL_BF16_TFLOPS if args.dtype == "bf16" else None,
+                    "frac_of_empirical": dom["tflops"] / EMPIRICAL_BF16_TFLOPS if args.dtype == "bf16" else None,
                     "traffic": pmc_traffic(dom["kernel"]) if args.mode == "train" and args.dtype == "bf16" else None,
                     "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
                     "flop_per_launch": dom["gflop_per_launch"] * 1e9,
@@ -608,6 +624,7 @@ def main():
                                        if args.mode == "train" else "model(x) under no_grad + threshold, input resident in HBM"},
             "roofline": roofline,
             "hbm_leg": hbm,
+            "step_ms": step_stats,
             "final_value": final_loss,
         }
         if nominal_gflop_img:

@@ -137,6 +137,10 @@ def run_batch(tensors, meta, model, mask_dir, overlay_dir, thresh, min_area, px_
             _write_outputs(mask, df, fpath, name, mask_dir, overlay_dir)
         else:
             writers[1].append(writers[0].submit(_write_outputs, mask, df, fpath, name, mask_dir, overlay_dir))
+            # back-pressure: at most ~4 batches of masks / tables wait for the writers; waiting on the OLDEST write also surfaces a
+            # failed write while the run is still going
+            while len(writers[1]) > writers[2]:
+                writers[1].popleft().result()
 
 
 def build_parser():
@@ -175,7 +179,7 @@ def main(argv=None):
     from concurrent.futures import ThreadPoolExecutor
     nthreads = max(1, min(8, (os.cpu_count() or 2) // 2))
     with ThreadPoolExecutor(nthreads) as dec_pool, ThreadPoolExecutor(nthreads) as wr_pool:
-        writers = (wr_pool, [])
+        writers = (wr_pool, deque(), 4 * max(1, args.batch))
         ahead = deque()
         it = iter(images)
 

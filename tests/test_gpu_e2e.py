@@ -239,6 +239,53 @@ def test_full_size_eval_mask_fp32():
           f"{int(flips.sum())} flips inside the band")
 
 
+def test_full_size_eval_mask_bf16_agreement_with_fp32_reference():
+    """The THROUGHPUT configuration against north_star's mask criterion, stated as measured: bs 8, 512 x 512 x 1, calibrated
+    50/50 mask (same recipe as the fp32 test above), bf16 eval forward on the device vs the fp32 CPU path.  bf16 storage cannot
+    be bit-exact after the threshold -- the fp32 path is (test above) -- so this test PRINTS and bounds what it is: the fraction
+    of pixels whose mask equals the fp32 reference's, the worst |dz| among the pixels that flip, and the same two figures
+    against the bf16-storage evaluation of the reference (oracle emulate_bf16=True), which shows how much of the disagreement
+    is bf16 storage itself rather than this implementation.  A flipped pixel must lie within the measured logit error of the
+    threshold: no flip may come from anything but rounding."""
+    torch.manual_seed(11)
+    from models.model_2 import UNetDC
+    model = UNetDC(in_channels=1, out_channels=1)
+    recipe.perturb_bn(model.state_dict(), 12)
+    model.eval()
+    x = recipe.seeded_input(13, (8, 1, 512, 512))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        _, z32 = otc.unet_forward(x, sd, dict(model.DILATIONS), train=False, return_logits=True)
+        _, zem = otc.unet_forward(x, sd, dict(model.DILATIONS), train=False, return_logits=True, emulate_bf16=True)
+    shift = recipe.LOGIT_THRESH - float(z32.median())
+    with torch.no_grad():
+        model.out_conv.bias += shift
+    z32, zem = (z32 + shift).double(), (zem + shift).double()
+    model = model.cuda()
+    model.set_compute_dtype("bf16")
+    with torch.no_grad():
+        p = model(x.cuda()).cpu()
+    z = logit(p)
+    mask = (p > 0.3).numpy()
+    rows = {}
+    for tag, zr in (("fp32 reference", z32), ("bf16-storage reference", zem)):
+        mref = (zr > recipe.LOGIT_THRESH).numpy()
+        flips = mask != mref
+        dz = (z - zr).abs().numpy()
+        dist = (zr - recipe.LOGIT_THRESH).abs().numpy()
+        rows[tag] = (1.0 - float(flips.mean()), float(dz.max()), float(dz.mean()), float(dist[flips].max()) if flips.any() else 0.0,
+                     float(dz[flips].max()) if flips.any() else 0.0)
+        # a flip is only legitimate where the reference logit sits closer to the threshold than the logit error there
+        assert np.all(dist[flips] <= dz[flips] + 1e-7), tag
+    a32, aem = rows["fp32 reference"], rows["bf16-storage reference"]
+    print("[full-size bf16 eval mask] " + "; ".join(
+        f"vs {k}: {v[0] * 100:.3f} % of 2097152 pixels equal, max|dz| {v[1]:.3e}, mean|dz| {v[2]:.3e}, farthest flipped pixel "
+        f"{v[3]:.3e} from the threshold, worst |dz| among flips {v[4]:.3e}" for k, v in rows.items()))
+    assert 0.3 < float((z32 > recipe.LOGIT_THRESH).double().mean()) < 0.7
+    assert a32[0] > 0.97 and aem[0] > 0.97, (a32, aem)
+    assert a32[1] < 0.25, a32                              # logits: bf16 storage, 23 layers deep (the fp32 path: < 1e-3)
+
+
 def test_full_size_bf16_gradients_vs_bf16_emulating_oracle():
     """Headline configuration (bs 8, 512x512x1, bf16 storage, fp32 accumulate) on the same batch as
     two CPU evaluations of the reference: plain fp32, and fp32 with the SAME bf16 storage points

@@ -20,4 +20,4 @@ for d in sorted(glob.glob(f"gpurun_out/pmc_*_{r}")):
         out[os.path.basename(d)[4:]] = json.load(open(f))
 json.dump(out, open(f"profiles/{r}_sq_counters.json", "w"), indent=1)
 PY
-python3 tools/render_docs.py $r
+

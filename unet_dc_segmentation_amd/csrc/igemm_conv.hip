@@ -339,11 +339,18 @@ int launch_igemm(IgemmParams& p, int dtype, hipStream_t stream) {
     UNETDC_REQUIRE(p.stats && p.bn_y && p.scale && p.shift && p.bn_mean && p.bn_rstd, "igemm: BN-backward inputs missing");
   {
     const long howo = (long)p.Ho * p.Wo;
-    static int no_p2 = -1;                       // UNETDC_NO_P2=1: take the division paths everywhere (debugging)
-    if (no_p2 < 0) no_p2 = getenv("UNETDC_NO_P2") ? 1 : 0;
-    const bool p2 = !no_p2 && (p.Wo & (p.Wo - 1)) == 0 && (howo & (howo - 1)) == 0;
+    const bool p2 = (p.Wo & (p.Wo - 1)) == 0 && (howo & (howo - 1)) == 0;
     p.wo_shift = p2 ? __builtin_ctz((unsigned)p.Wo) : -1;
     p.howo_shift = p2 ? __builtin_ctzl((unsigned long)howo) : -1;
+  }
+  if (p.in_scale) {
+    // input normalisation on load exists in the lattice kernel ONLY: no A/B switch may route this call to a kernel that would
+    // read the raw tensor as if it were the activation
+    if (!igemm_lattice_bnin_supported(p, dtype)) {
+      set_error("igemm: input normalisation asked for a shape / configuration the lattice kernel does not take");
+      return UNETDC_EUNSUPPORTED;
+    }
+    return launch_igemm_lattice(p, stream);
   }
   if (igemm_choice() == 0 && igemm_lattice_supported(p, dtype)) return launch_igemm_lattice(p, stream);
   if (igemm_choice() == 0 && igemm_halo_supported(p, dtype)) return launch_igemm_halo(p, dtype, stream);

@@ -139,7 +139,6 @@ __global__ __launch_bounds__(512, 2) void igemm_dma16_kernel(const IgemmParams p
   }
   const int nkc = p.Cin / KE;
   const int nsteps = __popc(tapmask) * nkc;
-  const bool stagger = p.dbg != 1;                 // UNETDC_DMA16_STAGGER=0 (A/B): every wave issues before its MFMAs
 
   // fragment read offsets: row c of a tile, chunk 4*g + rb (swizzle is the same for every 16-row tile)
   const int c16 = lane & 15, rb = lane >> 4;
@@ -196,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void igemm_dma16_kernel(const IgemmParams p
   // second half after them -- while one wave waits for the texture-address unit to take its DMA instructions the other one
   // feeds the matrix pipe (profiles/r03_dma16_step_decomposition.txt: in lock step the two costs add up, 0.45 + 0.21 us on
   // 0.70 us per step).  A stage issued late still has one whole step to land: three-stage ring only.
-  const bool late = NS == 3 && stagger && wave >= NW / 2;
+  const bool late = NS == 3 && wave >= NW / 2;
   int cur = 0, fill = NS - 1;
   for (int s = 0; s < nsteps; ++s) {
     if (NS > 2 && s + NS - 2 < nsteps) wait_vmcnt<(NS - 2) * PER>(); else wait_vmcnt<0>();
@@ -289,13 +288,8 @@ static int launch_dma16_cfg(IgemmParams& p, hipStream_t stream) {
   p.mblocks = ceil_div(p.M, BM);
   p.nblocks = p.Cout / BN;
   // 16 x 16 pixel blocks as M tiles for strongly dilated 3 x 3 convolutions (header comment): every padded tap-pixel pair is skipped
-  static int quad_on = -1;                               // UNETDC_QUAD=0: row-major blocks (A/B measurements)
-  if (quad_on < 0) { const char* e = getenv("UNETDC_QUAD"); quad_on = (e && e[0] == '0') ? 0 : 1; }
-  static int stagger = -1;
-  if (stagger < 0) { const char* e = getenv("UNETDC_DMA16_STAGGER"); stagger = (e && e[0] == '0') ? 0 : 1; }
-  p.dbg = stagger ? 0 : 1;
   p.quad_bpr = p.quad_bpi = 0;
-  if (quad_on && BM == 256 && p.ntaps == 9 && p.stride == 1 && p.mode != MODE_SHUFFLE && p.Ho == p.Hi && p.Wo == p.Wi &&
+  if (BM == 256 && p.ntaps == 9 && p.stride == 1 && p.mode != MODE_SHUFFLE && p.Ho == p.Hi && p.Wo == p.Wi &&
       p.offy[8] >= 16 && p.offy[8] % 16 == 0 && p.offx[8] == p.offy[8] && p.Ho % 16 == 0 && p.Wo % 16 == 0 &&
       p.M % ((long)p.Ho * p.Wo) == 0) {
     p.quad_bpr = p.Wo / 16;
@@ -318,11 +312,10 @@ bool igemm_dma16_supported(const IgemmParams& p, int dtype) {
 
 // cfg: 1 = 256x256 (8 waves), 2 = 256x128 (8 waves), 3 = 256x64 (4 waves) -- chosen by launch_igemm_dma
 int launch_igemm_dma16(IgemmParams& p, int cfg, hipStream_t stream) {
-  static int ring3 = -1;                                 // UNETDC_DMA16_RING=2: two-stage pipeline everywhere (A/B); 3: also 256 x 64
-  if (ring3 < 0) { const char* e = getenv("UNETDC_DMA16_RING"); ring3 = e ? atoi(e) : 1; }
+  // ring depth per tile (settled in round 3, profiles/r03_dma16_tile_configs.txt): three stages where they fit
   if (cfg == 1) return launch_dma16_cfg<2, 4, 8, 2>(p, stream);              // 3 x 64 KB does not fit
-  if (cfg == 2) return ring3 != 2 ? launch_dma16_cfg<4, 2, 4, 3>(p, stream) : launch_dma16_cfg<4, 2, 4, 2>(p, stream);
-  return ring3 == 3 ? launch_dma16_cfg<4, 1, 4, 3>(p, stream) : launch_dma16_cfg<4, 1, 4, 2>(p, stream);
+  if (cfg == 2) return launch_dma16_cfg<4, 2, 4, 3>(p, stream);
+  return launch_dma16_cfg<4, 1, 4, 2>(p, stream);
 }
 
 }  // namespace unetdc

@@ -55,9 +55,10 @@ struct LatticeParams {
   unsigned mg_nblocks, mg_tpi, mg_tpp, mg_d, mg_tx;   // ceil(2^32 / divisor) for the item decode (exact for n * divisor < 2^32)
   int stat_rows;              // statistics rows with data = gridDim.x / nblocks (one per workgroup and n-block), 0: per-tile rows
   int mtiles;                 // N * tiles_per_img = M / 256: rows [stat_rows, mtiles) are written as zeros
-  int dbg;                    // UNETDC_LAT_DBG (timing experiments only, results invalid): 1 no tap barriers, 2 no DMA waits, 8 no DMA
-  int prio;                   // 1: s_setprio 1 through the tap loops, 0 in the epilogue (UNETDC_LAT_PRIO=0 turns it off: A/B)
 };
+// s_setprio 1 through the tap loops, 0 in the epilogues (settled in round 3, profiles/r03_setprio_ab.txt).
+// The round-2/3 timing probes that removed barriers / waits / DMAs (UNETDC_LAT_DBG: invalid results) are gone from the library;
+// tools/probes/ keeps the notes.
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // patch slices issued at tap t: PJ slices in groups of SPT over the first taps
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
   };
   float tot_su = 0.f, tot_sq = 0.f;               // lanes tid < BN: running statistics of channel nblk * BN + tid
   auto epilogue = [&](const Item& it) {
-    if (q.prio) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(0);
     bool tile_ok[MT];
     unsigned voff[MT], yoff[MT];
     item_offsets(it, voff, yoff);
@@ -358,14 +359,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
         tot_sq += sq;
       }
     }
-    if (q.prio) __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(1);
     zero_acc();
   };
 
   // ---- the pipeline ----------------------------------------------------------------------------------------------------
   // flat step q = 9*chunk + tap over all (item, K chunk) pairs of this workgroup; weights of step q live in ring stage
   // tap % 3 and are issued at step q - 2; the patch of chunk c lives in buffer c % NPB.
-  if (q.prio) __builtin_amdgcn_s_setprio(1);
+  __builtin_amdgcn_s_setprio(1);
   Item cur = decode(first), nxt = cur;
   int item = first;
   load_consts(cur.nblk);
@@ -398,8 +399,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         // ---- wait for the weights of this step (and, at t = 0, the patch of this chunk) -------------------------------
-        if (q.dbg & 2) {
-        } else if (NPB == 2) {
+        if (NPB == 2) {
           constexpr int nA = lat_nsl<PJ, SPT>(0);
           if (t == 0) { if (boundary) wait_vmcnt<BI + NST>(); else wait_vmcnt<BI>(); }
           else if (t == 1) { if (boundary) wait_vmcnt<BI + nA + NST>(); else wait_vmcnt<BI + nA>(); }
@@ -417,13 +417,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
           else if (t > YT && NY) { if (last_kc) wait_vmcnt<BI + NY>(); else wait_vmcnt<BI>(); }
           else wait_vmcnt<BI>();
         }
-        if (!(q.dbg & 1)) raw_barrier();
+        raw_barrier();
         if (INORM && t == 0) normalise_patch(cur, kc);       // the patch of this chunk has landed (every wave's pieces)
         // ---- prefetch: weights two steps ahead, patch slices of the next chunk -----------------------------------------
-        if (q.dbg & 8) {
-        } else if (t < 7) issue_w((t + 2) % 3, t + 2, kc, cur.nblk, true);
+        if (t < 7) issue_w((t + 2) % 3, t + 2, kc, cur.nblk, true);
         else issue_w((t + 2) % 3, t + 2 - 9, kc_n, nblk_n, have_n);
-        if (NPB == 2 && !(q.dbg & 8)) {
+        if (NPB == 2) {
 #pragma unroll
           for (int u = 0; u < SPT; ++u)
             if (t * SPT + u < PJ) issue_slice(t * SPT + u, cbuf ^ 1, pb_n, pe_n);
@@ -438,8 +437,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
       if (NPB == 1) {
         raw_barrier();                            // every wave has issued the MFMAs of tap 8: the patch buffer is free
 #pragma unroll
-        for (int sl = 0; sl < PJ; ++sl)
-          if (!(q.dbg & 8)) issue_slice(sl, 0, pb_n, pe_n);
+        for (int sl = 0; sl < PJ; ++sl) issue_slice(sl, 0, pb_n, pe_n);
       }
       boundary = last_kc;
       if (last_kc) epilogue(cur);
@@ -671,7 +669,7 @@ __global__ __launch_bounds__(256, 2) void igemm_lattice_wide_kernel(const IgemmP
   };
   float tot_su = 0.f, tot_sq = 0.f;               // lanes tid < BN: running statistics of channel nblk * BN + tid
   auto epilogue = [&](const Item& it) {
-    if (q.prio) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(0);
     bool tile_ok[MT];
     unsigned voff[MT], yoff[MT];
     item_offsets(it, voff, yoff);
@@ -725,7 +723,7 @@ __global__ __launch_bounds__(256, 2) void igemm_lattice_wide_kernel(const IgemmP
         tot_sq += sq;
       }
     }
-    if (q.prio) __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(1);
     zero_acc();
   };
 
@@ -736,7 +734,7 @@ __global__ __launch_bounds__(256, 2) void igemm_lattice_wide_kernel(const IgemmP
   // "Two waves per SIMD").  The tap loops run at priority 1 and the epilogue (300-600 VALU instructions per item) at 0, so
   // that a workgroup in its MFMA phase is not held up by its neighbour's epilogue: -0.05 ... -0.07 ms per training step,
   // three of three interleaved pairs (profiles/r03_setprio_ab.txt).
-  if (q.prio) __builtin_amdgcn_s_setprio(1);
+  __builtin_amdgcn_s_setprio(1);
   Item cur = decode(first), nxt = cur;
   int item = first;
   load_consts(cur.nblk);
@@ -911,14 +909,6 @@ int launch_igemm_lattice(IgemmParams& p, hipStream_t stream) {
   q.tiles_per_img = q.d * q.d * q.tiles_x * q.tiles_y;
   q.nkc = p.Cin / 64;
   auto magic = [](unsigned dv) { return dv <= 1 ? 0u : (unsigned)(((1ull << 32) + dv - 1) / dv); };
-  {
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("UNETDC_LAT_DBG"); dbg = e ? atoi(e) : 0; }
-    q.dbg = dbg;
-    static int prio = -1;
-    if (prio < 0) { const char* e = getenv("UNETDC_LAT_PRIO"); prio = (e && e[0] == '0') ? 0 : 1; }
-    q.prio = prio;
-  }
   const int nimg = (int)((long)p.M / ((long)p.Ho * p.Wo));
   q.mtiles = nimg * q.tiles_per_img;              // = M / 256
   const bool wide = p.Cout % 128 == 0;

@@ -32,7 +32,6 @@ struct IgemmParams {
   const float* in_shift;
   int offy[9];
   int offx[9];
-  int dbg;                   // igemm_dma16: 1 = UNETDC_DMA16_STAGGER=0 (A/B switch)
 };
 int launch_igemm(IgemmParams& p, int dtype, hipStream_t stream);
 int igemm_mblocks(long M, int Cout);

@@ -420,7 +420,7 @@ __device__ __forceinline__ void ring_split_step(f32x16 (&acc)[5][2], const unsig
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same wave roles on v_mfma_f32_16x16x32_bf16 (M16 = true, the default; UNETDC_WGRAD_M16=0 selects the 32x32x16 form).
+// The same wave roles on v_mfma_f32_16x16x32_bf16 (M16 = true: the form that is built and launched).
 // These kernels are power bound like the convolutions (igemm_dma16.hip): MI355X_MICROARCH.md measures 1.12-1.15x the FLOP/s
 // for the 16x16x32 shape at equal cycles per FLOP with operands re-read from LDS.  LDS traffic per FLOP is unchanged (a
 // fragment is still two transposed 8-byte reads per lane for 512 multiply-adds per lane), the accumulators are the same
@@ -939,10 +939,9 @@ long wgrad_fused_workspace_bytes(int N, int H, int W, int CI, int CJ, int dtype)
 
 // Fills the slabs; the caller reduces `units` slabs with wgrad_reduce_kernel.
 bool wgrad_bnin_supported(int N, int H, int W, int CI, int CJ, int lda, int ldb, int d, int dtype) {
-  static int m16s = -1, splits = -1;
-  if (m16s < 0) { const char* e = getenv("UNETDC_WGRAD_M16"); m16s = (e && e[0] == '0') ? 0 : 1; }
+  static int splits = -1;
   if (splits < 0) { const char* e = getenv("UNETDC_WGRAD_SPLIT"); splits = (e && e[0] == '0') ? 0 : 1; }
-  return dtype == UNETDC_BF16 && m16s && splits && wgrad_fused_supported(N, H, W, CI, CJ, lda, ldb, d, 9, 1, dtype) &&
+  return dtype == UNETDC_BF16 && splits && wgrad_fused_supported(N, H, W, CI, CJ, lda, ldb, d, 9, 1, dtype) &&
          ring_pf(d, dtype) > 0;
 }
 
@@ -961,9 +960,9 @@ int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* 
   const int pf = ring_pf(d, dtype);
   static int split = -1;                                 // UNETDC_WGRAD_SPLIT=0: quadrant ring kernel (A/B)
   if (split < 0) { const char* e = getenv("UNETDC_WGRAD_SPLIT"); split = (e && e[0] == '0') ? 0 : 1; }
-  static int m16 = -1;                                   // UNETDC_WGRAD_M16=0: the 32x32x16 form of the tap-split kernels (A/B)
-  if (m16 < 0) { const char* e = getenv("UNETDC_WGRAD_M16"); m16 = (e && e[0] == '0') ? 0 : 1; }
-  if (in_scale && !(pf && dtype == UNETDC_BF16 && split && m16)) {
+  // (the tap-split kernels run on v_mfma_f32_16x16x32_bf16: settled in round 3, profiles/r03_wgrad_m16_ab.txt; the 32x32x16
+  //  instantiations are no longer built)
+  if (in_scale && !(pf && dtype == UNETDC_BF16 && split)) {
     set_error("wgrad (bnin): the input-normalising form exists for the 16x16x32 tap-split ring kernel only");
     return UNETDC_EUNSUPPORTED;
   }
@@ -977,10 +976,8 @@ int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* 
       *units_out = (W / fused_seg(dtype)) * ((N + ipu - 1) / ipu);
       nwg = (long)*units_out * p.itiles * p.jtiles;
     }
-    const void* fn = pf == 2 ? (m16 ? reinterpret_cast<const void*>(&wgrad_ring_split_kernel<2, true>)
-                                    : reinterpret_cast<const void*>(&wgrad_ring_split_kernel<2, false>))
-                             : (m16 ? reinterpret_cast<const void*>(&wgrad_ring_split_kernel<1, true>)
-                                    : reinterpret_cast<const void*>(&wgrad_ring_split_kernel<1, false>));
+    const void* fn = pf == 2 ? reinterpret_cast<const void*>(&wgrad_ring_split_kernel<2, true>)
+                             : reinterpret_cast<const void*>(&wgrad_ring_split_kernel<1, true>);
     static bool split_attr[3] = {false, false, false};
     if (!split_attr[pf]) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
@@ -1007,12 +1004,9 @@ int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* 
       note_kernel(pf == 2 ? "wgrad_ring_split_kernel<2, 16x16x32> bnin" : "wgrad_ring_split_kernel<1, 16x16x32> bnin");
       return check_launch("wgrad_ring_split_kernel(bnin)");
     }
-    if (pf == 2 && m16) hipLaunchKernelGGL((wgrad_ring_split_kernel<2, true>), dim3((unsigned)nwg), dim3(256), lds, stream, p);
-    else if (pf == 2) hipLaunchKernelGGL((wgrad_ring_split_kernel<2, false>), dim3((unsigned)nwg), dim3(256), lds, stream, p);
-    else if (m16) hipLaunchKernelGGL((wgrad_ring_split_kernel<1, true>), dim3((unsigned)nwg), dim3(256), lds, stream, p);
-    else hipLaunchKernelGGL((wgrad_ring_split_kernel<1, false>), dim3((unsigned)nwg), dim3(256), lds, stream, p);
-    note_kernel(pf == 2 ? (m16 ? "wgrad_ring_split_kernel<2, 16x16x32>" : "wgrad_ring_split_kernel<2, 32x32x16>")
-                        : (m16 ? "wgrad_ring_split_kernel<1, 16x16x32>" : "wgrad_ring_split_kernel<1, 32x32x16>"));
+    if (pf == 2) hipLaunchKernelGGL((wgrad_ring_split_kernel<2, true>), dim3((unsigned)nwg), dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((wgrad_ring_split_kernel<1, true>), dim3((unsigned)nwg), dim3(256), lds, stream, p);
+    note_kernel(pf == 2 ? "wgrad_ring_split_kernel<2, 16x16x32>" : "wgrad_ring_split_kernel<1, 16x16x32>");
     return check_launch("wgrad_ring_split_kernel");
   }
   if (pf) {
@@ -1049,8 +1043,7 @@ int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* 
   if (dtype == UNETDC_BF16 && split) {                   // d = 4, 8 in bf16: tap-split wave roles on the three-segment staging
     static bool sattr = false;
     if (!sattr) {
-      hipError_t e = hipFuncSetAttribute(m16 ? reinterpret_cast<const void*>(&wgrad_fused_split_kernel<true>)
-                                             : reinterpret_cast<const void*>(&wgrad_fused_split_kernel<false>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fused_split_kernel<true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       if (e != hipSuccess) {
         set_error("hipFuncSetAttribute(wgrad_fused_split_kernel) failed: %s", hipGetErrorString(e));
@@ -1058,9 +1051,8 @@ int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* 
       }
       sattr = true;
     }
-    if (m16) hipLaunchKernelGGL(wgrad_fused_split_kernel<true>, dim3((unsigned)nwg), dim3(256), lds, stream, p);
-    else hipLaunchKernelGGL(wgrad_fused_split_kernel<false>, dim3((unsigned)nwg), dim3(256), lds, stream, p);
-    note_kernel(m16 ? "wgrad_fused_split_kernel<16x16x32>" : "wgrad_fused_split_kernel<32x32x16>");
+    hipLaunchKernelGGL(wgrad_fused_split_kernel<true>, dim3((unsigned)nwg), dim3(256), lds, stream, p);
+    note_kernel("wgrad_fused_split_kernel<16x16x32>");
     return check_launch("wgrad_fused_split_kernel");
   }
   static bool attr_done[2] = {false, false};

@@ -64,9 +64,9 @@ class FusedAdam(torch.optim.Optimizer):
         """torch.optim.Adam's layout: every parameter's entry carries its OWN ``step`` tensor (the shared counter object is
         an internal economy; handing it out would make a non-fused torch Adam advance it once per parameter)."""
         sd = super().state_dict()
-        for st in sd["state"].values():
-            if "step" in st:
-                st["step"] = torch.tensor(float(self._step))
+        # torch.optim.Optimizer.state_dict() hands out the LIVE per-parameter dicts: build copies, never assign into them
+        sd["state"] = {k: (dict(st, step=torch.tensor(float(self._step))) if "step" in st else st)
+                       for k, st in sd["state"].items()}
         return sd
 
     def load_state_dict(self, state_dict):
