@@ -14,6 +14,8 @@ gradients per large tensor: cosine > 0.93 against the emulation and > 0.80 again
 deep-layer gradients of a randomly initialised network to cosine ~0.90 from fp32 whatever computes them (DESIGN.md section 2);
 that the optimisation nevertheless follows the fp32 trajectory is checked over 30 steps in test_gpu_training.py.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -281,6 +283,11 @@ def test_full_size_eval_mask_bf16_agreement_with_fp32_reference():
     print("[full-size bf16 eval mask] " + "; ".join(
         f"vs {k}: {v[0] * 100:.3f} % of 2097152 pixels equal, max|dz| {v[1]:.3e}, mean|dz| {v[2]:.3e}, farthest flipped pixel "
         f"{v[3]:.3e} from the threshold, worst |dz| among flips {v[4]:.3e}" for k, v in rows.items()))
+    if os.path.isdir("gpurun_out"):                        # (the figures DESIGN.md section 2 quotes)
+        with open("gpurun_out/bf16_eval_mask_agreement.txt", "w") as f:
+            for k, v in rows.items():
+                f.write(f"vs {k}: equal {v[0] * 100:.4f} % of 2097152 pixels; max|dz| {v[1]:.4e}; mean|dz| {v[2]:.4e}; farthest flipped "
+                        f"pixel {v[3]:.4e} from the threshold; worst |dz| among flips {v[4]:.4e}\n")
     assert 0.3 < float((z32 > recipe.LOGIT_THRESH).double().mean()) < 0.7
     assert a32[0] > 0.97 and aem[0] > 0.97, (a32, aem)
     assert a32[1] < 0.25, a32                              # logits: bf16 storage, 23 layers deep (the fp32 path: < 1e-3)

@@ -3,6 +3,7 @@
 
     python tools/op_bench.py fwd 8 512 512 64 64 1 bf16 [reps]
     python tools/op_bench.py convt_fwd 8 256 256 128 64 1 bf16      (h, w = INPUT size; also convt_dgrad, convt_wgrad)
+    python tools/op_bench.py fwd_bnin 8 512 512 64 64 1 bf16        (also dgrad_bnstats, wgrad_bnin: the level-1 forms)
 """
 import os
 import sys
@@ -40,8 +41,32 @@ if is_t:
     tws = G.workspace(tws_bytes)
 
 
+if op in ("fwd_bnin", "dgrad_bnstats", "wgrad_bnin"):
+    import ctypes
+    f32 = dict(device="cuda", dtype=torch.float32)
+    sc_in, sh_in = torch.rand(cin, **f32) + 0.5, torch.randn(cin, **f32) * 0.3
+    mu_in, rs_in = torch.randn(cin, **f32) * 0.1, torch.rand(cin, **f32) + 0.5
+    rows = _lib.load().unetdc_conv3x3_stats_rows(n * h * w, max(cin, cout))
+    stats = torch.empty((rows + 64) * 3 * max(cin, cout), **f32)
+    yprev = torch.randn(n * h * w, cin, generator=g).to(G.TD[dtype]).cuda()
+    npart = ctypes.c_int(0)
+    wws_bytes = _lib.load().unetdc_conv3x3_wgrad_workspace(n, h, w, cin, cout, DTI)
+    wws = G.workspace(wws_bytes)
+    dwt = torch.empty(cout, cin, 3, 3, device="cuda")
+
+
 def run():
-    if op == "fwd":
+    if op == "fwd_bnin":
+        _lib.call("unetdc_conv3x3_fwd_bnin", x.data_ptr(), cin, sc_in.data_ptr(), sh_in.data_ptr(), wf.data_ptr(), bias.data_ptr(),
+                  y.data_ptr(), cout, stats.data_ptr(), n, h, w, cin, cout, d, DTI, G.stream())
+    elif op == "dgrad_bnstats":
+        _lib.call("unetdc_conv3x3_dgrad_bnstats", dy.data_ptr(), cout, wd.data_ptr(), dx.data_ptr(), cin, yprev.data_ptr(), cin,
+                  sc_in.data_ptr(), sh_in.data_ptr(), mu_in.data_ptr(), rs_in.data_ptr(), stats.data_ptr(), stats.numel(),
+                  ctypes.byref(npart), n, h, w, cin, cout, d, DTI, G.stream())
+    elif op == "wgrad_bnin":
+        _lib.call("unetdc_conv3x3_wgrad_bnin", x.data_ptr(), cin, sc_in.data_ptr(), sh_in.data_ptr(), dy.data_ptr(), cout,
+                  dwt.data_ptr(), wws.data_ptr(), wws_bytes, n, h, w, cin, cout, d, DTI, G.stream())
+    elif op == "fwd":
         G.conv3x3_fwd(x, wf, bias, n, h, w, cin, cout, d, dtype, y, stats=True)
     elif op == "convt_fwd":
         _lib.call("unetdc_convT2x2_fwd", x.data_ptr(), cin, twf.data_ptr(), bias.data_ptr(), up.data_ptr(), 2 * cout,

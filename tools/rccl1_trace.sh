@@ -1,0 +1,13 @@
+#!/bin/bash
+# One-rank RCCL rehearsal under the kernel trace (GPU box, repo root):  tools/rccl1_trace.sh <tag>
+# UNETDC_DP_FORCE=1 makes bench.py build a ONE-rank process group and really issue every bucket's ncclAllReduce behind the HIP
+# backward (dp.py, single_rank_collectives).  The trace shows where RCCL's kernels land between the persistent compute kernels.
+tag=${1:-r04_rccl1}
+export TMPDIR=/tmp
+export UNETDC_DP_FORCE=1
+out=$PWD/gpurun_out/prof_$tag
+rm -rf $out; mkdir -p $out
+rocprofv3 --kernel-trace --output-format csv -d $out -o p -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench.json 2> $out/err.log || { echo "rocprofv3 failed"; tail -5 $out/err.log; exit 1; }
+f=$(find $out -name '*kernel_trace.csv' | head -1)
+python3 tools/rccl_trace_summary.py "$f" > gpurun_out/${tag}_trace.txt
+head -60 gpurun_out/${tag}_trace.txt

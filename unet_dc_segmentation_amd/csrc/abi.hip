@@ -332,7 +332,9 @@ int unetdc_convT2x2_dgrad(const void* dup, int lddup, const void* w_dgrad, void*
 }
 
 int64_t unetdc_convT2x2_wgrad_workspace(int n, int h, int w, int cin, int cout, int dtype) {
-  return wgrad_workspace_bytes((long)n * h * w, cin, cout, 4, dtype);
+  const long a = wgrad_workspace_bytes((long)n * h * w, cin, cout, 4, dtype);
+  const long b = convt_wgrad_fused_workspace_bytes(n, h, w, cin, cout);          // the tap-fused kernel may be chosen
+  return a > b ? a : b;
 }
 
 int unetdc_convT2x2_wgrad(const void* x, int ldx, const void* dup, int lddup, float* dw, void* workspace,

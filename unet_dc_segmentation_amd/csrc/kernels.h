@@ -60,6 +60,11 @@ bool wgrad_bnin_supported(int N, int H, int W, int CI, int CJ, int lda, int ldb,
 long wgrad_workspace_bytes(long P, int CI, int CJ, int ntaps, int dtype);
 long wgrad_fused_workspace_bytes(int N, int H, int W, int CI, int CJ, int dtype);
 long wgrad_rect_workspace_bytes(int N, int H, int W, int CI, int CJ, int d);
+// convt_wgrad.hip: tap-fused ConvTranspose2d weight gradient (bf16): X staged once for the four taps
+bool convt_wgrad_fused_supported(int N, int H, int W, int CI, int CJ, int ldx, int lddy, int dtype);
+long convt_wgrad_fused_workspace_bytes(int N, int H, int W, int CI, int CJ);
+int launch_convt_wgrad_fused(const void* x, int ldx, const void* dy, int lddy, float* part, int N, int H, int W, int CI, int CJ,
+                             int* units_out, hipStream_t stream);
 
 struct FirstParams {
   const float* x;        // [N][Cin][H][W] fp32

@@ -340,6 +340,23 @@ int launch_wgrad(WgradParams& p, float* out, void* workspace, long workspace_byt
                        wgrad_bnin_supported(p.N, p.H, p.W, p.CI, p.CJ, p.lda, p.ldb, p.offy[8], dtype),
                    "wgrad (bnin): shape not supported by the input-normalising kernel");
   }
+  if (!p.in_scale && wgrad_choice() == 0 && p.ntaps == 4 && p.stride == 2 && p.Hb == 2 * p.H && p.Wb == 2 * p.W &&
+      p.offy[3] == 1 && p.offx[3] == 1 && convt_wgrad_fused_supported(p.N, p.H, p.W, p.CI, p.CJ, p.lda, p.ldb, dtype)) {
+    // ConvTranspose2d(2, 2): one GEMM [Cin] x [4 Cout] with the input staged once for the four taps (convt_wgrad.hip)
+    const long need_c = convt_wgrad_fused_workspace_bytes(p.N, p.H, p.W, p.CI, p.CJ);
+    if (need_c > workspace_bytes) {
+      set_error("wgrad: workspace too small (%ld < %ld bytes)", workspace_bytes, need_c);
+      return UNETDC_EWORKSPACE;
+    }
+    int units = 0;
+    int rc = launch_convt_wgrad_fused(p.a, p.lda, p.b, p.ldb, reinterpret_cast<float*>(workspace), p.N, p.H, p.W, p.CI, p.CJ,
+                                      &units, stream);
+    if (rc != UNETDC_OK) return rc;
+    const long n = (long)p.CI * p.CJ * 4;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, stream,
+                       reinterpret_cast<float*>(workspace), out, units, 4, p.CI, p.CJ);
+    return check_launch("wgrad_reduce_kernel");
+  }
   if (!p.in_scale && wgrad_choice() == 0 && p.Hb == p.H && p.Wb == p.W &&
       wgrad_rect_supported(p.N, p.H, p.W, p.CI, p.CJ, p.lda, p.ldb, p.offy[8], p.ntaps, p.stride, dtype))
     return launch_wgrad_rect(p.a, p.lda, p.b, p.ldb, out, workspace, workspace_bytes, p.N, p.H, p.W, p.CI, p.CJ, p.offy[8],

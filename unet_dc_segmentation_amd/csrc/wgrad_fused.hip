@@ -32,6 +32,7 @@ struct WgradFusedParams {
   int N, H, W, CI, CJ, lddy, ldx, d;
   int ysplit, rows_per_unit, itiles, jtiles;
   int imgs_per_unit;   // tap-split ring kernel with ysplit == 1: a workgroup walks this many images of its segment in turn
+  int half_lds;        // paired form (HV = 2): LDS bytes of one half's ring
   // input normalisation ("bnin", tap-split ring kernel): x is the RAW conv output of the producing stage; every X row is
   // normalised in LDS, relu(in_scale * x + in_shift) rounded through bf16, once, when it has landed
   const float* in_scale;
@@ -517,8 +518,10 @@ __device__ __forceinline__ void split_step(SplitAcc<true>& A, const unsigned cha
 
 // tap 4: tg 1's half (slot 0) joins tg 0's (slot 4) through LDS (fixed order), then the partial slab part[unit][t][i][j]:
 // tg 0 stores taps 0..4, tg 1 taps 5..8.  The caller guarantees that every DMA has landed and every fragment has been read.
-__device__ __forceinline__ void split_finish(SplitAcc<false>& A, unsigned char* smem, const WgradFusedParams& p, int unit,
-                                             int i0, int j0, int qj, int tg, int lane) {
+template <int HV>
+__device__ __forceinline__ void split_finish(SplitAcc<false>& A, unsigned char* smem, unsigned char*, int,
+                                             const WgradFusedParams& p, int unit, int i0, int j0, int qj, int tg, int lane) {
+  static_assert(HV == 1, "the paired form exists on the 16x16x32 shape only");
   float* xch = reinterpret_cast<float*>(smem);
   __syncthreads();
   if (tg == 1) {
@@ -547,8 +550,14 @@ __device__ __forceinline__ void split_finish(SplitAcc<false>& A, unsigned char* 
     }
   }
 }
-__device__ __forceinline__ void split_finish(SplitAcc<true>& A, unsigned char* smem, const WgradFusedParams& p, int unit,
-                                             int i0, int j0, int qj, int tg, int lane) {
+// PAIRED FORM (HV = 2, 512 threads): the workgroup is two halves of four waves with the roles above, each half walking its
+// own half of the unit's image rows through its own LDS ring; here the second half hands its accumulators to the first
+// through LDS (ex: [wave of the half][register quad][lane], 144 KB of the then idle rings) and only the first half stores.
+// Why: the fp32 slabs are the accumulator state of the whole chip (2 x 256 threads x 160 registers per CU = 84 MB per launch),
+// written once and re-read by the reduce kernel; two K ranges that meet in LDS halve both (round 4).
+template <int HV>
+__device__ __forceinline__ void split_finish(SplitAcc<true>& A, unsigned char* smem, unsigned char* smem_all, int half,
+                                             const WgradFusedParams& p, int unit, int i0, int j0, int qj, int tg, int lane) {
   float* xch = reinterpret_cast<float*>(smem);             // [qj][co tile][ci tile][v][lane]: 16 KB
   __syncthreads();
   if (tg == 1) {
@@ -567,6 +576,30 @@ __device__ __forceinline__ void split_finish(SplitAcc<true>& A, unsigned char* s
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int v = 0; v < 4; ++v) A.a[4][c][j][v] += xch[(((qj * 4 + c) * 2 + j) * 4 + v) * 64 + lane];
+  }
+  if (HV == 2) {
+    __syncthreads();                                       // both halves are done with their tap-4 exchange areas
+    f32x4* ex = reinterpret_cast<f32x4*>(smem_all) + (tg == 0 ? qj * 40 : 80 + qj * 32) * 64 + lane;
+    if (half == 1) {
+#pragma unroll
+      for (int sl = 0; sl < 5; ++sl) {
+        if (tg == 1 && sl == 0) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) ex[(((sl - (tg == 1 ? 1 : 0)) * 4 + c) * 2 + j) * 64] = A.a[sl][c][j];
+      }
+    }
+    __syncthreads();
+    if (half == 1) return;
+#pragma unroll
+    for (int sl = 0; sl < 5; ++sl) {
+      if (tg == 1 && sl == 0) continue;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) A.a[sl][c][j] += ex[(((sl - (tg == 1 ? 1 : 0)) * 4 + c) * 2 + j) * 64];
+    }
   }
   // accumulator element v of a 16 x 16 tile: row (co) 4 * (lane >> 4) + v, column (ci) lane & 15
   const int col = lane & 15, rq = lane >> 4;
@@ -604,7 +637,7 @@ template <bool M16> __device__ __forceinline__ int split_src_chunk(int row, int 
   return M16 ? Frag16::src_chunk(row, pc) : Frag<bf16_t, 1>::src_chunk(row, pc);
 }
 
-template <int PF, int TG, bool M16, bool INORM>
+template <int PF, int TG, bool M16, bool INORM, int HV>
 __device__ __forceinline__ void ring_split_body(const WgradFusedParams& p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using T = bf16_t;
@@ -618,11 +651,14 @@ __device__ __forceinline__ void ring_split_body(const WgradFusedParams& p) {
   constexpr int NQ = (GI + 3) / 4;
   constexpr int DYB = SEG * RB, XB = XR * RB;
   constexpr int NDY = PF + 1;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  // paired form: tid / wave count inside the half, every LDS address is relative to the half's ring
+  const int half = HV == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
+  unsigned char* const smem = smem_all + half * p.half_lds;
   unsigned char* const xring = smem + NDY * DYB;
   const unsigned lds_base = lds_addr_of(smem);
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x & 255, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qj = wave & 1;
   constexpr int tg = TG;
@@ -640,8 +676,11 @@ __device__ __forceinline__ void ring_split_body(const WgradFusedParams& p) {
   const int ipu = p.imgs_per_unit > 1 ? p.imgs_per_unit : 1;
   const int n0 = (strip / segs) * ipu, x0 = (strip - (strip / segs) * segs) * SEG;
   int n = n0;
-  const int ybeg = ys * p.rows_per_unit;
-  const int yend = min(ybeg + p.rows_per_unit, p.H);
+  // paired form: the unit's rows are cut in two equal parts (the host only pairs when rows_per_unit is even and divides H:
+  // both halves then run the same number of steps and meet at every workgroup barrier)
+  const int rows_h = HV == 2 ? p.rows_per_unit / 2 : p.rows_per_unit;
+  const int ybeg = ys * p.rows_per_unit + half * rows_h;
+  const int yend = min(ybeg + rows_h, p.H);
   const int nsteps = yend - ybeg;
 
   const unsigned dybytes = (unsigned)((long)p.N * p.H * p.W * p.lddy * ES);
@@ -769,20 +808,20 @@ __device__ __forceinline__ void ring_split_body(const WgradFusedParams& p) {
   }
   }                                                      // images of this unit
 
-  // every DMA has landed (vmcnt(0) on the last step); join of tap 4 and the slab stores
-  split_finish(acc, smem, p, unit, i0, j0, qj, tg, lane);
+  // every DMA has landed (vmcnt(0) on the last step); join of tap 4, (paired form) of the two halves, and the slab stores
+  split_finish<HV>(acc, smem, smem_all, half, p, unit, i0, j0, qj, tg, lane);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int PF, bool M16, bool INORM = false>
-__global__ __launch_bounds__(256, 2) void wgrad_ring_split_kernel(const WgradFusedParams p) {
+template <int PF, bool M16, bool INORM = false, int HV = 1>
+__global__ __launch_bounds__(256 * HV, 2) void wgrad_ring_split_kernel(const WgradFusedParams p) {
   // the tap group is wave-uniform: two specialisations of the whole body, so the 160 accumulator registers of a wave
   // never meet in a phi (a per-step branch made the allocator spill ~590 registers)
-  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7) == 0) ring_split_body<PF, 0, M16, INORM>(p);
-  else ring_split_body<PF, 1, M16, INORM>(p);
+  if (__builtin_amdgcn_readfirstlane((int)((threadIdx.x >> 7) & 1)) == 0) ring_split_body<PF, 0, M16, INORM, HV>(p);
+  else ring_split_body<PF, 1, M16, INORM, HV>(p);
 }
 
-template <int TG, bool M16>
+template <int TG, bool M16, int HV>
 __device__ __forceinline__ void fused_split_body(const WgradFusedParams& p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using T = bf16_t;
@@ -796,9 +835,11 @@ __device__ __forceinline__ void fused_split_body(const WgradFusedParams& p) {
   constexpr int DYB = SEG * RB, XB = XR * RB;
   constexpr int STAGE = DYB + 3 * XB;
   static_assert(SEG % RPI == 0 && XR % RPI == 0, "segment/instruction mismatch");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  const int half = HV == 2 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;      // paired form: see split_finish
+  unsigned char* const smem = smem_all + half * p.half_lds;
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x & 255, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned lds_base = lds_addr_of(smem);
   const int qj = wave & 1;
@@ -812,8 +853,9 @@ __device__ __forceinline__ void fused_split_body(const WgradFusedParams& p) {
   const int segs = p.W / SEG;
   const int ys = unit % p.ysplit, strip = unit / p.ysplit;
   const int n = strip / segs, x0 = (strip - n * segs) * SEG;
-  const int ybeg = ys * p.rows_per_unit;
-  const int yend = min(ybeg + p.rows_per_unit, p.H);
+  const int rows_h = HV == 2 ? p.rows_per_unit / 2 : p.rows_per_unit;
+  const int ybeg = ys * p.rows_per_unit + half * rows_h;
+  const int yend = min(ybeg + rows_h, p.H);
 
   const unsigned dybytes = (unsigned)((long)p.N * p.H * p.W * p.lddy * ES);
   const unsigned xbytes = (unsigned)((long)p.N * p.H * p.W * p.ldx * ES);
@@ -876,16 +918,16 @@ __device__ __forceinline__ void fused_split_body(const WgradFusedParams& p) {
     split_step<TG>(acc, sdy, sx, sx + XB, sx + 2 * XB, lane, qj, p.d, offs);
   }
 
-  // every DMA has landed (vmcnt(0) on the last step); join of tap 4 and the slab stores
-  split_finish(acc, smem, p, unit, i0, j0, qj, tg, lane);
+  // every DMA has landed (vmcnt(0) on the last step); join of tap 4, (paired form) of the two halves, and the slab stores
+  split_finish<HV>(acc, smem, smem_all, half, p, unit, i0, j0, qj, tg, lane);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
 // tap-split form of the three-segment kernel (d = 4, 8): same staging, the wave roles of wgrad_ring_split_kernel
-template <bool M16>
-__global__ __launch_bounds__(256, 2) void wgrad_fused_split_kernel(const WgradFusedParams p) {
-  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 7) == 0) fused_split_body<0, M16>(p);
-  else fused_split_body<1, M16>(p);
+template <bool M16, int HV = 1>
+__global__ __launch_bounds__(256 * HV, 2) void wgrad_fused_split_kernel(const WgradFusedParams p) {
+  if (__builtin_amdgcn_readfirstlane((int)((threadIdx.x >> 7) & 1)) == 0) fused_split_body<0, M16, HV>(p);
+  else fused_split_body<1, M16, HV>(p);
 }
 
 // LDS bytes of the ring kernel, or 0 when the configuration does not leave room for two workgroups per CU
@@ -965,6 +1007,68 @@ int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* 
   if (in_scale && !(pf && dtype == UNETDC_BF16 && split)) {
     set_error("wgrad (bnin): the input-normalising form exists for the 16x16x32 tap-split ring kernel only");
     return UNETDC_EUNSUPPORTED;
+  }
+  // PAIRED FORM (round 4): 512-thread workgroups whose two halves walk the two halves of a unit's rows and meet in LDS
+  // (split_finish): half as many fp32 slabs written and reduced.  The plan is the one above at a target of 256 workgroups
+  // (one per CU: the two rings fill the LDS), i.e. every half does exactly the work a 256-thread workgroup did.
+  // UNETDC_WGRAD_PAIR=0: unpaired form (A/B).
+  static int pair = -1;
+  if (pair < 0) { const char* e = getenv("UNETDC_WGRAD_PAIR"); pair = (e && e[0] == '0') ? 0 : 1; }
+  // (three-segment staging, d = 4 / 8, waits for ALL its DMAs at every step: in lock step the two halves expose that wait
+  //  together -- measured 155.4 vs 157.9 us at d = 4 but 175.3 vs 166.3 us at d = 8, profiles/r04_wgrad_pair_ab.txt)
+  if (pair && dtype == UNETDC_BF16 && split && (pf || d <= 4)) {
+    const int strips = N * (W / fused_seg(dtype)), tiles = p.itiles * p.jtiles;
+    int ys = 256 / (strips * tiles);
+    if (ys < 1) ys = 1;
+    if (ys > H / 16) ys = H / 16 > 0 ? H / 16 : 1;
+    const int rows = (H + ys - 1) / ys;
+    const int half_lds = pf ? ring_lds(d, dtype, pf) + (in_scale ? 512 : 0)
+                            : 2 * (fused_seg(dtype) * 128 + 3 * (fused_seg(dtype) + 16) * 128);
+    if (rows % 2 == 0 && H % rows == 0 && 2 * half_lds <= 160 * 1024) {
+      WgradFusedParams q = p;
+      q.rows_per_unit = rows;
+      q.ysplit = H / rows;
+      q.half_lds = half_lds;
+      int un = strips * q.ysplit;
+      long nwg2 = (long)un * tiles;
+      if (pf && q.ysplit == 1 && nwg2 > 256 && N > 1) {   // several images per workgroup (as in the unpaired form, target 256)
+        int ipu = (int)((nwg2 + 255) / 256);
+        if (ipu > N) ipu = N;
+        q.imgs_per_unit = ipu;
+        un = (W / fused_seg(dtype)) * ((N + ipu - 1) / ipu);
+        nwg2 = (long)un * tiles;
+      }
+      const int lds2 = 160 * 1024;                         // two rings, and 144 KB of them for the hand-over at the end
+      const void* fn2;
+      if (!pf) fn2 = reinterpret_cast<const void*>(&wgrad_fused_split_kernel<true, 2>);
+      else if (in_scale) fn2 = pf == 2 ? reinterpret_cast<const void*>(&wgrad_ring_split_kernel<2, true, true, 2>)
+                                       : reinterpret_cast<const void*>(&wgrad_ring_split_kernel<1, true, true, 2>);
+      else fn2 = pf == 2 ? reinterpret_cast<const void*>(&wgrad_ring_split_kernel<2, true, false, 2>)
+                         : reinterpret_cast<const void*>(&wgrad_ring_split_kernel<1, true, false, 2>);
+      static const void* attr_set[8] = {nullptr};
+      bool have = false;
+      for (int i = 0; i < 8; ++i) have = have || attr_set[i] == fn2;
+      if (!have) {
+        hipError_t e = hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        if (e != hipSuccess) {
+          set_error("hipFuncSetAttribute(paired wgrad kernel) failed: %s", hipGetErrorString(e));
+          return UNETDC_ELAUNCH;
+        }
+        for (int i = 0; i < 8; ++i)
+          if (!attr_set[i]) { attr_set[i] = fn2; break; }
+      }
+      *units_out = un;
+      const dim3 g((unsigned)nwg2), b(512);
+      if (!pf) hipLaunchKernelGGL((wgrad_fused_split_kernel<true, 2>), g, b, lds2, stream, q);
+      else if (in_scale && pf == 2) hipLaunchKernelGGL((wgrad_ring_split_kernel<2, true, true, 2>), g, b, lds2, stream, q);
+      else if (in_scale) hipLaunchKernelGGL((wgrad_ring_split_kernel<1, true, true, 2>), g, b, lds2, stream, q);
+      else if (pf == 2) hipLaunchKernelGGL((wgrad_ring_split_kernel<2, true, false, 2>), g, b, lds2, stream, q);
+      else hipLaunchKernelGGL((wgrad_ring_split_kernel<1, true, false, 2>), g, b, lds2, stream, q);
+      note_kernel(!pf ? "wgrad_fused_split_kernel<16x16x32> paired"
+                      : (in_scale ? (pf == 2 ? "wgrad_ring_split_kernel<2, 16x16x32> paired bnin" : "wgrad_ring_split_kernel<1, 16x16x32> paired bnin")
+                                  : (pf == 2 ? "wgrad_ring_split_kernel<2, 16x16x32> paired" : "wgrad_ring_split_kernel<1, 16x16x32> paired")));
+      return check_launch("paired wgrad kernel");
+    }
   }
   if (pf && dtype == UNETDC_BF16 && split) {
     const int lds = ring_lds(d, dtype, pf) + (in_scale ? 512 : 0);
