@@ -203,19 +203,31 @@ __global__ __launch_bounds__(512, 2) void igemm_dma16_kernel(const IgemmParams p
     const bool more = s + NS - 1 < nsteps;
     if (more && !late) issue(fill);
     const unsigned char* base = smem + cur * STAGE;
+    {
+      // ONE exposed LDS latency per step instead of two (round 4): the B fragments of BOTH 32-channel halves and the A
+      // fragments of the first are read up front (in-order returns: the first MFMA waits for its own two operands only);
+      // fa[i] is re-loaded with the second half's fragment right behind the four MFMAs that read it (A-fragment-major
+      // order), so the second half starts with everything in registers.
+      u32x4 fa[TMT], fb[2][4];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      u32x4 fa[TMT], fb[4];
+      for (int j = 0; j < 4; ++j) fb[0][j] = ld16(base + b_rd[0] + j * 16 * 128);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = ld16(base + b_rd[g] + j * 16 * 128);
+      for (int i = 0; i < TMT; ++i) fa[i] = ld16(base + a_rd[0] + i * 16 * 128);
 #pragma unroll
-      for (int i = 0; i < TMT; ++i) fa[i] = ld16(base + a_rd[g] + i * 16 * 128);
+      for (int j = 0; j < 4; ++j) fb[1][j] = ld16(base + b_rd[1] + j * 16 * 128);
 #pragma unroll
-      for (int i = 0; i < TMT; ++i)
+      for (int g = 0; g < 2; ++g)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
-                                                              acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TMT; ++i) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[g][j]),
+                                                                acc[i][j], 0, 0, 0);
+          if (g == 0) {
+            fa[i] = ld16(base + a_rd[1] + i * 16 * 128);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
     }
     if (more && late) issue(fill);
     cur = cur + 1 == NS ? 0 : cur + 1;

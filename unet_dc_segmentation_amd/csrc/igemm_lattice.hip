@@ -250,6 +250,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
   // (the 4-wave BatchNorm-backward variant also carries the prefetched saved outputs: there the two halves take turns
   //  in ONE fragment register set, everywhere else both halves are read up front)
   constexpr bool SPLIT_FRAGS = (MODE == MODE_BNBWD && NW == 4);
+  u32x4 fa_live[2][MT];
   auto compute_tap = [&](int ky, int kx, int stage, const int (&ab)[3][2]) {
     if (SPLIT_FRAGS) {
 #pragma unroll
@@ -269,23 +270,33 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
       }
       return;
     }
-    u32x4 fa[2][MT], fb[2][4];
+    // A FRAGMENTS LIVE ACROSS TAPS (round 4): fa[g][i] is re-loaded right behind the four MFMAs that read it with the
+    // fragment the NEXT tap needs there -- the patch is resident for the whole chunk, so those reads cross the tap barrier
+    // and only the eight B fragments of a tap (its weights are only known to have landed behind the barrier) are read in
+    // front of the MFMAs; the first tap of a chunk loads its A fragments itself (the patch has just landed / been normalised).
+    u32x4 fb[2][4];
+    const int t = ky * 3 + kx, nky = (t + 1) / 3, nkx = (t + 1) % 3;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) fb[g][j] = ld16(smem + boff[g] + stage * WST + j * 16 * 128);
+      if (t == 0) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
-        fa[g][i] = ld16(smem + ab[kx][g] + ((i >> 1) + ky) * (LPW * 128) + (i & 1) * (16 * 128));
+        for (int i = 0; i < MT; ++i)
+          fa_live[g][i] = ld16(smem + ab[kx][g] + ((i >> 1) + ky) * (LPW * 128) + (i & 1) * (16 * 128));
+      }
     }
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+      for (int i = 0; i < MT; ++i) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[g][i]),
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa_live[g][i]),
                                                               __builtin_bit_cast(bf16x8, fb[g][j]), acc[i][j], 0, 0, 0);
+        if (t < 8) fa_live[g][i] = ld16(smem + ab[nkx][g] + ((i >> 1) + nky) * (LPW * 128) + (i & 1) * (16 * 128));
+        __builtin_amdgcn_sched_barrier(0);
+      }
   };
 
   // ---- epilogue of one item -----------------------------------------------------------------------------------------------
@@ -612,27 +623,61 @@ __global__ __launch_bounds__(256, 2) void igemm_lattice_wide_kernel(const IgemmP
           for (int e = 0; e < 4; ++e) acc[ng][i][j][e] = binit[ng][j];
   };
 
-  // one tap: per 32-channel half 4 A + 8 B fragments, 32 MFMAs (the A fragments stay, the B fragments of the two 64-channel
-  // groups take turns in one register set)
-  auto compute_tap = [&](int ky, int kx, const int (&bb)[2], const int (&ab)[3][2]) {
+  // one tap = four groups of 16 MFMAs, (k half g, channel group ng) = (0,0) (0,1) (1,0) (1,1): 4 A fragments of half g x 4 B
+  // fragments of (g, ng).  FRAGMENT READS ARE ROLLED INTO THE MFMA STREAM (round 4).  The round-3 form read the 8 fragments
+  // of a group in front of its MFMAs: the ISA showed four exposed LDS latencies per tap -- a full one behind the barrier, a
+  // full one at g = 1, and the B fragments of the two ng = 1 groups issued with two MFMAs of cover -- about 600 cycles against
+  // 1024 cycles of MFMA work.  Now every fragment register is re-loaded right behind the LAST MFMA that reads it, with the
+  // operand it holds next: in the ng = 0 groups the MFMAs run B-fragment-major and fb[j] <- B(g, 1, j) after its four
+  // MFMAs (12 MFMAs of cover); in the ng = 1 groups they run A-fragment-major and fa[i] <- A of the next half -- or of the
+  // NEXT TAP's first half: the patch is resident for the whole chunk, so those reads cross the tap barrier; the B
+  // fragments of (1, 0) slip into the last A batch of (0, 1) one MFMA apart.  What stays exposed is B(0, 0) behind the tap
+  // barrier (the weights of a tap are only known to have landed there) and the A fragments of a chunk's first tap.
+  // No extra registers: the A set is live across the barrier instead of dead there.
+  u32x4 fa[MT];
+  auto lda = [&](int ky, int kx, int g, int i) {
+    return ld16(smem + aoff[kx][g] + ((i >> 1) + ky) * (LPW * 128) + (i & 1) * (16 * 128));
+  };
+  auto mma = [&](int ng, int i, int j, const u32x4& b) {
+    acc[ng][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, b),
+                                                            acc[ng][i][j], 0, 0, 0);
+  };
+  auto compute_tap = [&](int t, const int (&bb)[2]) {
+    const int ky = t / 3, kx = t % 3, nky = (t + 1) / 3, nkx = (t + 1) % 3;
+    u32x4 fb[4];
+    if (t == 0) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) fa[i] = lda(ky, kx, 0, i);
+    }
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-      u32x4 fa[MT];
+      if (g == 0) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i) fa[i] = ld16(smem + ab[kx][g] + ((i >> 1) + ky) * (LPW * 128) + (i & 1) * (16 * 128));
-#pragma unroll
-      for (int ng = 0; ng < NG; ++ng) {
-        u32x4 fb[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = ld16(smem + bb[g] + (ng * 4 + j) * 16 * 128);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[ng][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]),
-                                                                    __builtin_bit_cast(bf16x8, fb[j]), acc[ng][i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) fb[j] = ld16(smem + bb[0] + j * 16 * 128);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      // (g, 0): B-major, fb[j] <- B(g, 1, j) behind its last reader
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) mma(0, i, j, fb[j]);
+        fb[j] = ld16(smem + bb[g] + (4 + j) * 16 * 128);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // (g, 1): A-major, fa[i] <- A(next half / next tap's first half, i) behind its last reader
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          mma(1, i, j, fb[j]);
+          if (g == 0 && i == MT - 1) {             // last batch of (0, 1): fb[j] is free, B(1, 0, j) moves in
+            fb[j] = ld16(smem + bb[1] + j * 16 * 128);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (g == 0) fa[i] = lda(ky, kx, 1, i);
+        else if (t < 8) fa[i] = lda(nky, nkx, 0, i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
 
@@ -763,7 +808,7 @@ __global__ __launch_bounds__(256, 2) void igemm_lattice_wide_kernel(const IgemmP
         raw_barrier();
         if (t < 8) issue_w((par + t + 1) & 1, t + 1, kc, cur.nblk, true);
         else issue_w((par + 9) & 1, 0, kc_n, nblk_n, have_n);
-        if (t & 1) compute_tap(t / 3, t % 3, bb1, aoff); else compute_tap(t / 3, t % 3, bb0, aoff);
+        if (t & 1) compute_tap(t, bb1); else compute_tap(t, bb0);
       }
       raw_barrier();                              // every wave has issued the MFMAs of tap 8: the patch buffer is free
 #pragma unroll
@@ -931,7 +976,7 @@ int launch_igemm_lattice(IgemmParams& p, hipStream_t stream) {
     if (p.mode == MODE_BNBWD) return launch_lattice_wide_cfg<MODE_BNBWD>(p, q, stream);
     return launch_lattice_wide_cfg<MODE_AFFINE_RELU>(p, q, stream);
   }
-  if (wide) return launch_lattice_mode<4, 2, 4, 2>(p, q, 1, stream);
+  if (wide) return launch_lattice_cfg<4, 2, 4, 2, MODE_STORE>(p, q, 1, stream);   // (wide && !ww: the plain-store mode only)
   if (p.in_scale) return launch_lattice_cfg<4, 1, 4, 1, MODE_STATS, true>(p, q, 2, stream);      // igemm_lattice_bnin_supported
   return launch_lattice_mode<4, 1, 4, 1>(p, q, 2, stream);
 }
