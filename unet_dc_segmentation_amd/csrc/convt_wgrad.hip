@@ -114,7 +114,6 @@ __global__ __launch_bounds__(512, 2) void convt_wgrad_kernel(const ConvtWgradPar
   for (int s = 0; s < nsteps; ++s) {
     if (s + 1 < nsteps) wait_vmcnt<6>(); else wait_vmcnt<0>();       // this wave's pieces of stage s (stage s + 1 may stay in flight)
     raw_barrier();                                                    // everyone's; and everyone has issued the MFMAs of step s - 1
-    if (s + 2 < nsteps) issue(fill, s0 + s + 2);
     const unsigned char* st = smem + cur * CWG_STAGE;
     const unsigned char* sd = st + 8192 + wave * 4096;
     bf16x8 fb[4], fa[8];
@@ -122,6 +121,7 @@ __global__ __launch_bounds__(512, 2) void convt_wgrad_kernel(const ConvtWgradPar
     for (int j = 0; j < 4; ++j) fb[j] = Frag16::frag_at(sd, fo[j][0], fo[j][1]);
 #pragma unroll
     for (int c = 0; c < 8; ++c) fa[c] = Frag16::frag_at(st + (c >> 2) * 4096, fo[c & 3][0], fo[c & 3][1]);
+    if (s + 2 < nsteps) issue(fill, s0 + s + 2);                     // behind the fragment reads: in flight while the DMAs are accepted
 #pragma unroll
     for (int c = 0; c < 8; ++c)
 #pragma unroll

@@ -201,7 +201,6 @@ __global__ __launch_bounds__(512, 2) void igemm_dma16_kernel(const IgemmParams p
     if (NS > 2 && s + NS - 2 < nsteps) wait_vmcnt<(NS - 2) * PER>(); else wait_vmcnt<0>();
     raw_barrier();
     const bool more = s + NS - 1 < nsteps;
-    if (more && !late) issue(fill);
     const unsigned char* base = smem + cur * STAGE;
     {
       // ONE exposed LDS latency per step instead of two (round 4): the B fragments of BOTH 32-channel halves and the A
@@ -215,6 +214,7 @@ __global__ __launch_bounds__(512, 2) void igemm_dma16_kernel(const IgemmParams p
       for (int i = 0; i < TMT; ++i) fa[i] = ld16(base + a_rd[0] + i * 16 * 128);
 #pragma unroll
       for (int j = 0; j < 4; ++j) fb[1][j] = ld16(base + b_rd[1] + j * 16 * 128);
+      if (more && !late) issue(fill);              // behind the fragment reads: they are in flight while the DMAs are being accepted
 #pragma unroll
       for (int g = 0; g < 2; ++g)
 #pragma unroll

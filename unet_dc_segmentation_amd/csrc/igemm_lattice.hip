@@ -251,7 +251,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
   //  in ONE fragment register set, everywhere else both halves are read up front)
   constexpr bool SPLIT_FRAGS = (MODE == MODE_BNBWD && NW == 4);
   u32x4 fa_live[2][MT];
-  auto compute_tap = [&](int ky, int kx, int stage, const int (&ab)[3][2]) {
+  // `issue`: this tap's vector-memory statements (weights two taps ahead, patch slices, saved-output prefetch), placed BEHIND
+  // the tap's first fragment reads so that those are in flight while the wave gets its DMA instructions accepted
+  auto compute_tap = [&](int ky, int kx, int stage, const int (&ab)[3][2], auto&& issue) {
     if (SPLIT_FRAGS) {
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
@@ -260,6 +262,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
         for (int j = 0; j < 4; ++j) fb[j] = ld16(smem + boff[g] + stage * WST + j * 16 * 128);
 #pragma unroll
         for (int i = 0; i < MT; ++i) fa[i] = ld16(smem + ab[kx][g] + ((i >> 1) + ky) * (LPW * 128) + (i & 1) * (16 * 128));
+        if (g == 0) issue();
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -286,6 +289,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
           fa_live[g][i] = ld16(smem + ab[kx][g] + ((i >> 1) + ky) * (LPW * 128) + (i & 1) * (16 * 128));
       }
     }
+    issue();
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -431,19 +435,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
         raw_barrier();
         if (INORM && t == 0) normalise_patch(cur, kc);       // the patch of this chunk has landed (every wave's pieces)
         // ---- prefetch: weights two steps ahead, patch slices of the next chunk -----------------------------------------
-        if (t < 7) issue_w((t + 2) % 3, t + 2, kc, cur.nblk, true);
-        else issue_w((t + 2) % 3, t + 2 - 9, kc_n, nblk_n, have_n);
-        if (NPB == 2) {
+        auto issue = [&]() {
+          if (t < 7) issue_w((t + 2) % 3, t + 2, kc, cur.nblk, true);
+          else issue_w((t + 2) % 3, t + 2 - 9, kc_n, nblk_n, have_n);
+          if (NPB == 2) {
 #pragma unroll
-          for (int u = 0; u < SPT; ++u)
-            if (t * SPT + u < PJ) issue_slice(t * SPT + u, cbuf ^ 1, pb_n, pe_n);
-        }
-        if (MODE == MODE_BNBWD && t == YT && last_kc) {       // after this tap's DMAs: the y fetch is younger than W(q + 2)
-          unsigned voff[MT], yoff[MT];
-          item_offsets(cur, voff, yoff);
-          epi16_prefetch_y<MT>(p, yoff, 2u * (unsigned)d * ldyb, ypre);
-        }
-        compute_tap(t / 3, t % 3, t % 3, ab);
+            for (int u = 0; u < SPT; ++u)
+              if (t * SPT + u < PJ) issue_slice(t * SPT + u, cbuf ^ 1, pb_n, pe_n);
+          }
+          if (MODE == MODE_BNBWD && t == YT && last_kc) {     // after this tap's DMAs: the y fetch is younger than W(q + 2)
+            unsigned voff[MT], yoff[MT];
+            item_offsets(cur, voff, yoff);
+            epi16_prefetch_y<MT>(p, yoff, 2u * (unsigned)d * ldyb, ypre);
+          }
+        };
+        compute_tap(t / 3, t % 3, t % 3, ab, issue);
       }
       if (NPB == 1) {
         raw_barrier();                            // every wave has issued the MFMAs of tap 8: the patch buffer is free
@@ -642,7 +648,9 @@ __global__ __launch_bounds__(256, 2) void igemm_lattice_wide_kernel(const IgemmP
     acc[ng][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, b),
                                                             acc[ng][i][j], 0, 0, 0);
   };
-  auto compute_tap = [&](int t, const int (&bb)[2]) {
+  // `issue`: the DMA statements of this tap (next tap's weights).  They go BEHIND the tap's first fragment reads: the reads
+  // are in flight while the wave gets its four DMA instructions accepted (60-100 cycles each), instead of starting after them.
+  auto compute_tap = [&](int t, const int (&bb)[2], auto&& issue) {
     const int ky = t / 3, kx = t % 3, nky = (t + 1) / 3, nkx = (t + 1) % 3;
     u32x4 fb[4];
     if (t == 0) {
@@ -654,6 +662,7 @@ __global__ __launch_bounds__(256, 2) void igemm_lattice_wide_kernel(const IgemmP
       if (g == 0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[j] = ld16(smem + bb[0] + j * 16 * 128);
+        issue();
       }
       // (g, 0): B-major, fb[j] <- B(g, 1, j) behind its last reader
 #pragma unroll
@@ -806,9 +815,11 @@ __global__ __launch_bounds__(256, 2) void igemm_lattice_wide_kernel(const IgemmP
         // W(t) was issued one tap ago and nothing younger exists -- except, at t = 0 behind an item boundary, the epilogue stores
         if (t == 0 && boundary) wait_vmcnt<NST>(); else wait_vmcnt<0>();
         raw_barrier();
-        if (t < 8) issue_w((par + t + 1) & 1, t + 1, kc, cur.nblk, true);
-        else issue_w((par + 9) & 1, 0, kc_n, nblk_n, have_n);
-        if (t & 1) compute_tap(t, bb1); else compute_tap(t, bb0);
+        auto issue = [&]() {
+          if (t < 8) issue_w((par + t + 1) & 1, t + 1, kc, cur.nblk, true);
+          else issue_w((par + 9) & 1, 0, kc_n, nblk_n, have_n);
+        };
+        if (t & 1) compute_tap(t, bb1, issue); else compute_tap(t, bb0, issue);
       }
       raw_barrier();                              // every wave has issued the MFMAs of tap 8: the patch buffer is free
 #pragma unroll

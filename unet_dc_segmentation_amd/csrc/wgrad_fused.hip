@@ -460,9 +460,12 @@ __device__ __forceinline__ void split_zero(SplitAcc<true>& A) {
         for (int e = 0; e < 4; ++e) A.a[t][c][j][e] = 0.f;
 }
 
-template <int TG>
+// `issue`: the row's DMA statements, placed behind the step's first fragment reads (those are in flight while the wave gets
+// its DMA instructions accepted; round 4, as in igemm_lattice.hip)
+template <int TG, typename Issue>
 __device__ __forceinline__ void ring_split_step16(f32x4 (&acc)[5][4][2], const unsigned char* sdy, const unsigned char* sx0,
-                                                  const unsigned char* sx1, const unsigned char* sx2, const Split16Offs& o) {
+                                                  const unsigned char* sx1, const unsigned char* sx2, const Split16Offs& o,
+                                                  Issue&& issue) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NI = 9;
   // A (dY) fragments: ONE set of four, refilled in place for the second k32 step -- each one right behind the two MFMAs of
@@ -480,6 +483,7 @@ __device__ __forceinline__ void ring_split_step16(f32x4 (&acc)[5][4][2], const u
 #pragma unroll
   for (int c = 0; c < 4; ++c) load_a1(0, c);
   load_b(0);
+  issue();
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int k32 = s16_k32(TG, i);
@@ -503,17 +507,18 @@ __device__ __forceinline__ void ring_split_step16(f32x4 (&acc)[5][4][2], const u
 }
 
 // one image row of the strip: both forms behind one name
-template <int TG>
+template <int TG, typename Issue>
 __device__ __forceinline__ void split_step(SplitAcc<false>& A, const unsigned char* sdy, const unsigned char* sx0,
                                            const unsigned char* sx1, const unsigned char* sx2, int lane, int qj, int d,
-                                           const Split16Offs&) {
+                                           const Split16Offs&, Issue&& issue) {
+  issue();
   ring_split_step<TG>(A.a, sdy, sx0, sx1, sx2, lane, qj, d);
 }
-template <int TG>
+template <int TG, typename Issue>
 __device__ __forceinline__ void split_step(SplitAcc<true>& A, const unsigned char* sdy, const unsigned char* sx0,
                                            const unsigned char* sx1, const unsigned char* sx2, int, int, int,
-                                           const Split16Offs& o) {
-  ring_split_step16<TG>(A.a, sdy, sx0, sx1, sx2, o);
+                                           const Split16Offs& o, Issue&& issue) {
+  ring_split_step16<TG>(A.a, sdy, sx0, sx1, sx2, o, issue);
 }
 
 // tap 4: tg 1's half (slot 0) joins tg 0's (slot 4) through LDS (fixed order), then the partial slab part[unit][t][i][j]:
@@ -793,14 +798,16 @@ __device__ __forceinline__ void ring_split_body(const WgradFusedParams& p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       raw_barrier();
     }
-    if (s + PF < nsteps) {
-      issue_dy(gslot_dy, ybeg + s + PF);
-      issue_x(gslot_x, ybeg + s + PF + d);
-      gslot_dy = (gslot_dy + 1 == NDY) ? 0 : gslot_dy + 1;
-      gslot_x = (gslot_x + 1 == R) ? 0 : gslot_x + 1;
-    }
+    auto issue_row = [&]() {
+      if (s + PF < nsteps) {
+        issue_dy(gslot_dy, ybeg + s + PF);
+        issue_x(gslot_x, ybeg + s + PF + d);
+        gslot_dy = (gslot_dy + 1 == NDY) ? 0 : gslot_dy + 1;
+        gslot_x = (gslot_x + 1 == R) ? 0 : gslot_x + 1;
+      }
+    };
     const unsigned char* sdyp = smem + sdy * DYB;
-    split_step<TG>(acc, sdyp, xring + sl0 * XB, xring + sl1 * XB, xring + sl2 * XB, lane, qj, d, offs);
+    split_step<TG>(acc, sdyp, xring + sl0 * XB, xring + sl1 * XB, xring + sl2 * XB, lane, qj, d, offs, issue_row);
     sl0 = (sl0 + 1 == R) ? 0 : sl0 + 1;
     sl1 = (sl1 + 1 == R) ? 0 : sl1 + 1;
     sl2 = (sl2 + 1 == R) ? 0 : sl2 + 1;
@@ -912,10 +919,12 @@ __device__ __forceinline__ void fused_split_body(const WgradFusedParams& p) {
   for (int s = 0; s < nsteps; ++s) {
     wait_vmcnt<0>();                                   // asm DMA + raw barrier: see lds_dma.h
     raw_barrier();
-    if (s + 1 < nsteps) issue((s + 1) & 1, ybeg + s + 1);
+    auto issue_row = [&]() {
+      if (s + 1 < nsteps) issue((s + 1) & 1, ybeg + s + 1);
+    };
     const unsigned char* sdy = smem + (s & 1) * STAGE;
     const unsigned char* sx = sdy + DYB;
-    split_step<TG>(acc, sdy, sx, sx + XB, sx + 2 * XB, lane, qj, p.d, offs);
+    split_step<TG>(acc, sdy, sx, sx + XB, sx + 2 * XB, lane, qj, p.d, offs, issue_row);
   }
 
   // every DMA has landed (vmcnt(0) on the last step); join of tap 4, (paired form) of the two halves, and the slab stores
