@@ -865,6 +865,33 @@ def test_fused_bn_backward_statistics_are_run_to_run_deterministic(case):
             assert nbad == 0, f"{nbad} partial sums differ in run {it}"
 
 
+@pytest.mark.parametrize("case", [("conv", 8, 64, 64, 512, 512, 1), ("conv", 8, 256, 256, 64, 128, 2), ("conv", 8, 128, 128, 256, 256, 4),
+                                  ("conv", 8, 64, 64, 1024, 512, 1), ("convt", 8, 32, 32, 1024, 512, 1), ("convt", 8, 256, 256, 128, 64, 1)])
+def test_weight_gradients_are_run_to_run_deterministic(case):
+    """Full-size layers (bs 8): the paired tap-split weight gradients (two K ranges per workgroup meeting in LDS, fp32 slabs summed
+    in a fixed order) and the tap-fused ConvTranspose2d weight gradient -- three runs, bitwise identical."""
+    kind, n, h, w, cin, cout, d = case
+    g = gen(5)
+    lib = _lib.load()
+    x = torch.randn(n * h * w, cin, generator=g).bfloat16().cuda()
+    if kind == "conv":
+        dy = torch.randn(n * h * w, cout, generator=g).bfloat16().cuda()
+        runs = [G.conv3x3_wgrad(x, dy, n, h, w, cin, cout, d, "bf16") for _ in range(3)]
+    else:
+        dup = torch.randn(n * 4 * h * w, cout, generator=g).bfloat16().cuda()
+        nbytes = lib.unetdc_convT2x2_wgrad_workspace(n, h, w, cin, cout, G.DT["bf16"])
+        ws = G.workspace(nbytes)
+        runs = []
+        for _ in range(3):
+            dw = torch.full((cin, cout, 2, 2), float("nan"), device="cuda")
+            call("unetdc_convT2x2_wgrad", x.data_ptr(), cin, dup.data_ptr(), cout, dw.data_ptr(), ws.data_ptr(), nbytes, n, h, w,
+                 cin, cout, G.DT["bf16"], G.stream())
+            runs.append(dw)
+    torch.cuda.synchronize()
+    assert torch.isfinite(runs[0]).all()
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+
+
 @pytest.mark.parametrize("gamma", [2.0, 1.5])
 def test_fused_focal_dice_loss(gamma):
     """Fused HIP loss vs the reference's own numbers (golden) and vs the PyTorch formulation."""

@@ -31,6 +31,15 @@ print(f"last complete step: {len(step)} kernels, {(step[-1][1] - t0) / 1e6:.3f} 
 busy = sum(e - s for s, e, *_ in comp) / 1e6
 print(f"sum of compute kernel durations {busy:.3f} ms; sum of RCCL kernel durations {sum(e - s for s, e, *_ in coll) / 1e6:.3f} ms")
 
+# gaps on the compute queue (a collective may or may not explain them)
+gaps = []
+for a, b in zip(comp, comp[1:]):
+    g = b[0] - a[1]
+    if g > 3000:
+        inside = [n.replace("unetdc::", "").replace("void ", "")[:30] for s_, e_, n, _ in coll if s_ < b[0] and e_ > a[1]]
+        gaps.append((g / 1e3, a[2].replace("unetdc::", "").replace("void ", "")[:40], b[2].replace("unetdc::", "").replace("void ", "")[:40], inside))
+print(f"compute-queue gaps > 3 us: {len(gaps)}, total {sum(g[0] for g in gaps):.1f} us")
+
 
 def running_at(t):
     return [n for s, e, n, _ in comp if s <= t < e]
@@ -48,13 +57,5 @@ for s, e, n, q in coll:
     wait = (s - last[1]) / 1e3 if last else float("nan")
     print(f"{short(n):40s} {(s - t0) / 1e6:9.3f} {(e - s) / 1e3:8.1f} {q:>6s}  {[short(x)[:34] for x in running_at(s)]} | "
           f"{[short(x)[:34] for x in running_at(e - 1)]} | producer {short(last[2])[:34] if last else '-'} ended {wait:+.1f} us before the start")
-# gaps on the compute queue that a collective could explain
-gaps = []
-for a, b in zip(comp, comp[1:]):
-    g = b[0] - a[1]
-    if g > 3000:
-        inside = [short(n)[:30] for s, e, n, _ in coll if s < b[0] and e > a[1]]
-        gaps.append((g / 1e3, short(a[2])[:40], short(b[2])[:40], inside))
-print(f"compute-queue gaps > 3 us: {len(gaps)}, total {sum(g[0] for g in gaps):.1f} us")
 for g in sorted(gaps, reverse=True)[:25]:
     print(f"  {g[0]:7.1f} us between {g[1]} and {g[2]}  RCCL kernels inside: {g[3]}")

@@ -807,7 +807,13 @@ __device__ __forceinline__ void ring_split_body(const WgradFusedParams& p) {
       }
     };
     const unsigned char* sdyp = smem + sdy * DYB;
-    split_step<TG>(acc, sdyp, xring + sl0 * XB, xring + sl1 * XB, xring + sl2 * XB, lane, qj, d, offs, issue_row);
+    // (the input-normalising form keeps its DMA statements in front: behind the reads it measured 221.7 vs 214.5 us)
+    if (INORM) {
+      issue_row();
+      split_step<TG>(acc, sdyp, xring + sl0 * XB, xring + sl1 * XB, xring + sl2 * XB, lane, qj, d, offs, []() {});
+    } else {
+      split_step<TG>(acc, sdyp, xring + sl0 * XB, xring + sl1 * XB, xring + sl2 * XB, lane, qj, d, offs, issue_row);
+    }
     sl0 = (sl0 + 1 == R) ? 0 : sl0 + 1;
     sl1 = (sl1 + 1 == R) ? 0 : sl1 + 1;
     sl2 = (sl2 + 1 == R) ? 0 : sl2 + 1;
