@@ -144,7 +144,11 @@ __global__ __launch_bounds__(512, 2) void convt_wgrad_kernel(const ConvtWgradPar
 #pragma unroll
   for (int c = 0; c < 8; ++c)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[c][j] += ex[(c * 4 + j) * 64];
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 o = ex[(c * 4 + j) * 64];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[c][j][v] += o[v];                 // element by element: no packed-fp32 VALU (build guard)
+    }
   // accumulator element v of a 16 x 16 tile: row (ci) 4 * (lane >> 4) + v, column (co) lane & 15
   const int col = lane & 15, rq = lane >> 4;
   float* slab = p.part + ((long)ks * 4 + wave) * p.CI * p.CJ;

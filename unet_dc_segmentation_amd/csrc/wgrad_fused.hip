@@ -603,7 +603,11 @@ __device__ __forceinline__ void split_finish(SplitAcc<true>& A, unsigned char* s
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) A.a[sl][c][j] += ex[(((sl - (tg == 1 ? 1 : 0)) * 4 + c) * 2 + j) * 64];
+        for (int j = 0; j < 2; ++j) {
+          const f32x4 o = ex[(((sl - (tg == 1 ? 1 : 0)) * 4 + c) * 2 + j) * 64];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) A.a[sl][c][j][v] += o[v];          // element by element: no packed-fp32 VALU (build guard)
+        }
     }
   }
   // accumulator element v of a 16 x 16 tile: row (co) 4 * (lane >> 4) + v, column (ci) lane & 15

@@ -319,6 +319,10 @@ class UNetEngine:
         # recomputed); `generation` counts forwards so that a backward can tell whether ITS forward's activations
         # are still the ones in the buffers (see _UNetFunction.backward).
         self.generation = 0
+        # busy: the activations in the buffers belong to a live autograd graph (set by _UNetFunction.forward, cleared when its
+        # backward has run or its graph has been freed); the module gives another forward of this shape its own engine meanwhile
+        self.busy = False
+        self._busy_gen = -1
 
     # ------------------------------------------------------------------ weight caches
     def invalidate_weight_cache(self):
@@ -721,6 +725,12 @@ class UNetEngine:
         return flat
 
 
+def _release_engine(ref, generation):
+    eng = ref()
+    if eng is not None and eng.busy and eng._busy_gen == generation:
+        eng.busy = False
+
+
 class _UNetFunction(torch.autograd.Function):
     """Autograd boundary: one node for the whole network (forward kernels / backward kernels)."""
 
@@ -729,6 +739,10 @@ class _UNetFunction(torch.autograd.Function):
         probs = engine.forward(x, train=True, frozen=frozen)
         ctx.engine = engine
         ctx.generation = engine.generation
+        engine.busy, engine._busy_gen = True, engine.generation
+        # a forward that is never back-propagated releases its engine when its graph is freed
+        import weakref
+        weakref.finalize(ctx, _release_engine, weakref.ref(engine), engine.generation)
         # x (read by the first layer's weight gradient) and probs (read by the head backward) go through autograd's
         # saved-tensor machinery so that an in-place edit of either between forward and backward is detected
         ctx.save_for_backward(x, probs)
@@ -752,4 +766,7 @@ class _UNetFunction(torch.autograd.Function):
         for p, o in zip(eng.params, eng.poffs):
             grads.append(flat[o:o + p.numel()].view_as(p) if p.requires_grad else None)
         dx = eng.input_grad() if ctx.needs_input_grad[0] else None
+        # the gradients are enqueued: the next forward may take the buffers (a SECOND backward through a retained graph stays
+        # possible as long as no forward has used them in between -- the generation check above says so otherwise)
+        _release_engine(lambda: eng, ctx.generation)
         return (dx, None, None, *grads)

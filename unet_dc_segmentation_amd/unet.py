@@ -60,7 +60,7 @@ class _UNetFamily(nn.Module):
         #   "f32"  -- fp32 storage, exact-fp32 MFMA (parity configuration)
         #   "bf16" -- bf16 activations/weights, fp32 accumulate (throughput configuration)
         self.compute_dtype = "f32"
-        self._engines = {}               # (device, input shape) -> engine.UNetEngine, most recently used last
+        self._engines = {}               # (device, input shape) -> [engine.UNetEngine, ...], most recently used last
         self._weights = None             # engine.PackedWeights: compute-type weight images, shared by the engines
         self.grad_ready_hook = None      # set by the data-parallel wrapper (dp.py)
         self.grad_sync_finish = None
@@ -78,16 +78,37 @@ class _UNetFamily(nn.Module):
     def _engine_for(self, x):
         """One engine (activation buffers, schedule) per input shape, a few kept alive: the ragged last training and validation
         batches of train_DC_focal.py (its loaders have no drop_last, like the reference's) must not free and re-allocate the
-        full-batch buffers every epoch.  The packed weight images are shared (engine.PackedWeights)."""
+        full-batch buffers every epoch.  The packed weight images are shared (engine.PackedWeights).
+
+        An engine whose activations belong to a LIVE autograd graph (a forward under autograd whose backward has not run yet)
+        is busy: another forward of the same shape -- a second micro-batch before the first backward, a validation forward
+        between forward and backward -- gets its own engine instead of overwriting those activations, as the reference's plain
+        autograd module allows (models/model_2.py:56-80).  Sized for 288 GB: ~12 GB per live bs-8 512 x 512 bf16 forward."""
         from . import engine                           # raises if libunetdc_hip.so is missing
         key = (x.device, tuple(x.shape))
-        eng = self._engines.pop(key, None)
-        if eng is None or not eng.matches(x):
+        pool = self._engines.pop(key, [])
+        pool = [e for e in pool if e.matches(x)]
+        eng = next((e for e in pool if not e.busy), None)
+        if eng is None:
             eng = engine.UNetEngine(self, x, weights=self._weights)
             self._weights = eng.weights
-            while len(self._engines) >= self.MAX_ENGINES:
-                self._engines.pop(next(iter(self._engines)))          # least recently used
-        self._engines[key] = eng
+            pool.append(eng)
+            # least recently used shapes go first; busy engines are never dropped here (their graph still needs them)
+            while sum(len(v) for v in self._engines.values()) + len(pool) > self.MAX_ENGINES:
+                victim = next(((k, e) for k, v in self._engines.items() for e in v if not e.busy), None)
+                if victim is None:
+                    extra = next((e for e in pool if e is not eng and not e.busy), None)
+                    if extra is None:
+                        break
+                    pool.remove(extra)
+                    continue
+                self._engines[victim[0]].remove(victim[1])
+                if not self._engines[victim[0]]:
+                    del self._engines[victim[0]]
+        else:
+            pool.remove(eng)
+            pool.append(eng)                           # most recently used last
+        self._engines[key] = pool
         return eng
 
     def __getstate__(self):
@@ -101,7 +122,7 @@ class _UNetFamily(nn.Module):
     @property
     def _engine(self):
         """The most recently used engine (None before the first HIP forward)."""
-        return next(reversed(self._engines.values()), None) if self._engines else None
+        return next(reversed(self._engines.values()))[-1] if self._engines else None
 
     def dilation_of(self, block):
         return self.DILATIONS[block]
