@@ -168,8 +168,7 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const ApplyParams p)
   const T* __restrict__ yg = reinterpret_cast<const T*>(p.y);
   T* __restrict__ ag = reinterpret_cast<T*>(p.a);
   T* __restrict__ pg = reinterpret_cast<T*>(p.pooled);
-  for (long idx0 = (long)blockIdx.x * 256 + threadIdx.x; idx0 < total; idx0 += (long)gridDim.x * 256) {
-    const long idx = p.reverse ? total - 1 - idx0 : idx0;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int ch = (int)(idx % cpp);
     const long q = idx / cpp;
     const int c0 = ch * EPC;
@@ -258,8 +257,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const BnBwdParams p) {
     }
   }
   if (active) {
-    for (long q0 = (long)blockIdx.x * plane + pl; q0 < Q; q0 += (long)gridDim.x * plane) {
-      const long q = (APPLY && p.reverse) ? Q - 1 - q0 : q0;      // (the reduce pass keeps its order: its sums depend on it)
+    for (long q = (long)blockIdx.x * plane + pl; q < Q; q += (long)gridDim.x * plane) {
       if (!POOL) {
         float yv[EPC], g[EPC];
         Chunk<T>::unpack(ld16(yg + q * p.ldy + c0), yv);
@@ -834,17 +832,6 @@ int launch_bn_eval_affine(const float* gamma, const float* beta, const float* rm
   return check_launch("bn_eval_affine_kernel");
 }
 
-// BACK-TO-FRONT WALKS (round 4).  A pass that reads a tensor another kernel has JUST written or read front to back finds the
-// END of that tensor in the 256 MB Infinity Cache (memory side: MI355X_MICROARCH.md); walked front to back it starts with the
-// part that was evicted first and then evicts the rest ahead of itself.  The level-1 tensors are 268 MB each (8 x 512 x 512 x 64
-// bf16), the two-pass BatchNorm backward of a pooled stage reads 603 MB twice.  Pure re-ordering of independent elements:
-// bit-identical results.  UNETDC_REVERSE_WALK=0: front to back everywhere (A/B).
-static int reverse_walk() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("UNETDC_REVERSE_WALK"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v;
-}
-
 int launch_apply(ApplyParams& p, int dtype, hipStream_t stream) {
   const int epc = dtype == UNETDC_BF16 ? 8 : 4;
   UNETDC_REQUIRE(dtype == UNETDC_F32 || dtype == UNETDC_BF16, "bn_relu_apply: bad dtype %d", dtype);
@@ -857,7 +844,6 @@ int launch_apply(ApplyParams& p, int dtype, hipStream_t stream) {
   if (p.a) UNETDC_REQUIRE(p.lda % epc == 0, "bn_relu_apply: lda not chunk aligned");
   const long items = (long)p.N * (pool ? p.H / 2 : p.H) * (pool ? p.W / 2 : p.W) * (p.C / epc);
   const int nb = grid_for(items, 256);
-  p.reverse = reverse_walk();                     // y has just been written front to back by the convolution
   if (dtype == UNETDC_BF16) {
     if (pool) hipLaunchKernelGGL((bn_relu_apply_kernel<bf16_t, true>), dim3(nb), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((bn_relu_apply_kernel<bf16_t, false>), dim3(nb), dim3(256), 0, stream, p);
@@ -971,7 +957,6 @@ int launch_bn_bwd(BnBwdParams& p, const float* gamma, float* dgamma, float* dbet
   if (rc != UNETDC_OK) return rc;
   const long items = Q * cpp;
   const dim3 grid2(grid_for(items, 256) > 4096 ? 4096 : grid_for(items, 256), (cpp + seg - 1) / seg);
-  p.reverse = reverse_walk();                     // the reduce pass / the producers of dskip, y have just walked front to back
   if (p.head_w) {
     if (dtype == UNETDC_BF16) hipLaunchKernelGGL((bn_bwd_kernel<bf16_t, false, true, true>), grid2, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((bn_bwd_kernel<float, false, true, true>), grid2, dim3(256), 0, stream, p);
@@ -1048,7 +1033,6 @@ int launch_bn_bwd_pool_split(BnBwdParams& p, const float* gamma, float* dgamma, 
   if (rc != UNETDC_OK) return rc;
   const long items = Q * cpp;
   const dim3 grid2(grid_for(items, 256) > 4096 ? 4096 : grid_for(items, 256), (cpp + seg - 1) / seg);
-  p.reverse = reverse_walk();
   if (dtype == UNETDC_BF16) launch_bn_bwd_k<bf16_t>(p, true, true, grid2, stream);
   else launch_bn_bwd_k<float>(p, true, true, grid2, stream);
   return check_launch("bn_bwd_kernel(apply)");

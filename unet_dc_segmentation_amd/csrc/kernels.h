@@ -107,7 +107,6 @@ struct ApplyParams {
   const void* y; void* a; void* pooled;
   const float* scale; const float* shift;
   int N, H, W, C, ldy, lda, ldp;
-  int reverse;             // walk the tensor back to front (see reverse_walk() in elementwise.hip)
 };
 struct BnBwdParams {
   const void* dskip; const void* dpool; const void* y; void* dy;
@@ -119,7 +118,6 @@ struct BnBwdParams {
   // per pixel -- recomputed here from the fp32 [N, 1, H, W] tensors instead of being stored by the head backward and read
   // back (non-pooled apply pass only; rounded through the storage type like the stored tensor was)
   const float* head_dprobs; const float* head_probs; const float* head_w;
-  int reverse;             // apply pass: walk the tensor back to front (see reverse_walk() in elementwise.hip)
 };
 struct HeadParams {
   const void* a; const float* w; const float* b; float* probs;
