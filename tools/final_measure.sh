@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-end measurement set (GPU box, repo root):  tools/final_measure.sh <tag>     e.g. r02_final
 # Writes gpurun_out/<tag>_*; copy what should be judged into profiles/.
-tag=${1:-r03_final}
+tag=${1:-r04_final}
 export TMPDIR=/tmp
 set -e
 python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err                      # default run (with cpu_baseline)

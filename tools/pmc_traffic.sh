@@ -2,7 +2,7 @@
 # HBM-side traffic of every kernel of one training step:  tools/pmc_traffic.sh <tag>      (GPU box, repo root)
 # Two separate rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass), no trace domains, the program
 # itself after `--`.  Result: gpurun_out/<tag>_pmc_traffic.json (copy to profiles/ to have bench.py report it).
-tag=${1:-r03}
+tag=${1:-r04}
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/pmc_traffic_$tag
 mkdir -p $out
