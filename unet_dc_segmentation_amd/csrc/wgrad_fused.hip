@@ -377,48 +377,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_ring_kernel(const WgradFusedPara
 //                                         tg 1: taps 5..8 and tap 4 on the last two  (18 B fragments, 36 MFMAs each)
 //   per k16 step: 2 A fragments + 4.5 B fragments for 9 MFMAs  ->  1.44 LDS instructions per MFMA.
 // The two partial sums of tap 4 are added through LDS at the end, tg 0's + tg 1's (fixed order).
+// (That first form ran on v_mfma_f32_32x32x16_bf16; since round 3 only the 16x16x32 form below is built.)
 // ------------------------------------------------------------------------------------------------
-__host__ __device__ constexpr int split_item_k16(int tg, int i) {
-  return tg == 0 ? (i < 10 ? i / 5 : 2 + (i - 10) / 4) : (i < 8 ? i / 4 : 2 + (i - 8) / 5);
-}
-__host__ __device__ constexpr int split_item_tap(int tg, int i) {
-  return tg == 0 ? (i < 10 ? i % 5 : (i - 10) % 4) : (i < 8 ? 5 + i % 4 : 4 + (i - 8) % 5);
-}
-__host__ __device__ constexpr bool split_item_first(int tg, int i) {   // first item of its k16 step
-  return i == 0 || split_item_k16(tg, i) != split_item_k16(tg, i - 1);
-}
-
-template <int TG>
-__device__ __forceinline__ void ring_split_step(f32x16 (&acc)[5][2], const unsigned char* sdy, const unsigned char* sx0,
-                                                const unsigned char* sx1, const unsigned char* sx2, int lane, int qj, int d) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int NI = 18;
-  bf16x8 fa[2][2], fb[3];
-  auto load_a = [&](int k16) {
-    fa[k16 & 1][0] = Frag<bf16_t, 1>::frag(sdy, lane, 0, 16 * k16);
-    fa[k16 & 1][1] = Frag<bf16_t, 1>::frag(sdy, lane, 32, 16 * k16);
-  };
-  auto load_b = [&](int i) {
-    const int k16 = split_item_k16(TG, i), t = split_item_tap(TG, i), ky = t / 3, kx = t - 3 * ky;
-    const unsigned char* sx = ky == 0 ? sx0 : (ky == 1 ? sx1 : sx2);
-    fb[i % 3] = Frag<bf16_t, 1>::frag(sx, lane, qj * 32, 16 * k16 + kx * d);
-  };
-  load_a(0);
-  load_b(0);
-  load_b(1);
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    if (i + 2 < NI) load_b(i + 2);
-    const int k16 = split_item_k16(TG, i);
-    if (split_item_first(TG, i) && k16 + 1 < 4) load_a(k16 + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    const int slot = split_item_tap(TG, i) - (TG == 0 ? 0 : 4);
-    acc[slot][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[k16 & 1][0], fb[i % 3], acc[slot][0], 0, 0, 0);
-    acc[slot][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[k16 & 1][1], fb[i % 3], acc[slot][1], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#endif
-}
 
 // ------------------------------------------------------------------------------------------------
 // The same wave roles on v_mfma_f32_16x16x32_bf16 (M16 = true: the form that is built and launched).
@@ -438,17 +398,8 @@ struct Split16Offs {       // per-lane byte offsets of the transposed reads at k
 };
 
 template <bool M16> struct SplitAcc;
-template <> struct SplitAcc<false> { f32x16 a[5][2]; };
 template <> struct SplitAcc<true> { f32x4 a[5][4][2]; };
 
-__device__ __forceinline__ void split_zero(SplitAcc<false>& A) {
-#pragma unroll
-  for (int t = 0; t < 5; ++t)
-#pragma unroll
-    for (int ih = 0; ih < 2; ++ih)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) A.a[t][ih][e] = 0.f;
-}
 __device__ __forceinline__ void split_zero(SplitAcc<true>& A) {
 #pragma unroll
   for (int t = 0; t < 5; ++t)
@@ -508,13 +459,6 @@ __device__ __forceinline__ void ring_split_step16(f32x4 (&acc)[5][4][2], const u
 
 // one image row of the strip: both forms behind one name
 template <int TG, typename Issue>
-__device__ __forceinline__ void split_step(SplitAcc<false>& A, const unsigned char* sdy, const unsigned char* sx0,
-                                           const unsigned char* sx1, const unsigned char* sx2, int lane, int qj, int d,
-                                           const Split16Offs&, Issue&& issue) {
-  issue();
-  ring_split_step<TG>(A.a, sdy, sx0, sx1, sx2, lane, qj, d);
-}
-template <int TG, typename Issue>
 __device__ __forceinline__ void split_step(SplitAcc<true>& A, const unsigned char* sdy, const unsigned char* sx0,
                                            const unsigned char* sx1, const unsigned char* sx2, int, int, int,
                                            const Split16Offs& o, Issue&& issue) {
@@ -523,38 +467,6 @@ __device__ __forceinline__ void split_step(SplitAcc<true>& A, const unsigned cha
 
 // tap 4: tg 1's half (slot 0) joins tg 0's (slot 4) through LDS (fixed order), then the partial slab part[unit][t][i][j]:
 // tg 0 stores taps 0..4, tg 1 taps 5..8.  The caller guarantees that every DMA has landed and every fragment has been read.
-template <int HV>
-__device__ __forceinline__ void split_finish(SplitAcc<false>& A, unsigned char* smem, unsigned char*, int,
-                                             const WgradFusedParams& p, int unit, int i0, int j0, int qj, int tg, int lane) {
-  static_assert(HV == 1, "the paired form exists on the 16x16x32 shape only");
-  float* xch = reinterpret_cast<float*>(smem);
-  __syncthreads();
-  if (tg == 1) {
-#pragma unroll
-    for (int ih = 0; ih < 2; ++ih)
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) xch[((qj * 2 + ih) * 16 + reg) * 64 + lane] = A.a[0][ih][reg];
-  }
-  __syncthreads();
-  if (tg == 0) {
-#pragma unroll
-    for (int ih = 0; ih < 2; ++ih)
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) A.a[4][ih][reg] += xch[((qj * 2 + ih) * 16 + reg) * 64 + lane];
-  }
-  const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int sl = 0; sl < 5; ++sl) {
-    if (tg == 1 && sl == 0) continue;
-    const int t = sl + (tg == 0 ? 0 : 4);
-#pragma unroll
-    for (int ih = 0; ih < 2; ++ih) {
-      float* slab = p.part + ((long)unit * 9 + t) * p.CI * p.CJ + (long)(i0 + ih * 32 + 4 * h) * p.CJ + j0 + qj * 32 + r;
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) slab[(long)((reg & 3) + 8 * (reg >> 2)) * p.CJ] = A.a[sl][ih][reg];
-    }
-  }
-}
 // PAIRED FORM (HV = 2, 512 threads): the workgroup is two halves of four waves with the roles above, each half walking its
 // own half of the unit's image rows through its own LDS ring; here the second half hands its accumulators to the first
 // through LDS (ex: [wave of the half][register quad][lane], 144 KB of the then idle rings) and only the first half stores.
