@@ -24,19 +24,24 @@ SWITCH_SETS = {
 }
 
 
-@pytest.mark.parametrize("name", sorted(SWITCH_SETS))
-def test_operator_parity_under_switches(name):
-    env = dict(os.environ, UNETDC_TEST_THIN="1", **SWITCH_SETS[name])     # thinned shape lists: tests/test_gpu_ops.py
-    sel = "conv3x3_fwd_dgrad_wgrad or first_conv or conv_transpose or fused_bn_backward_statistics"
-    if name == "unfused_epilogues":
-        sel = "wgrad_tap_fused or conv3x3_fwd_dgrad_wgrad"
-    if name == "round1_kernels":
-        sel = "(" + sel + " or wgrad_tap_fused) and not f32"
-    cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_ops.py"), "-m", "gpu", "-x", "-q",
-           "-k", sel, "-p", "no:cacheprovider"]
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
+def test_operator_parity_under_switches():
+    """The three switch sets run as three child processes AT THE SAME TIME (the switches are read once per process; four
+    processes on the card, well inside the pool's limit of six): sequentially they were 1.5 minutes of the GPU suite."""
+    procs = {}
+    for name in sorted(SWITCH_SETS):
+        env = dict(os.environ, UNETDC_TEST_THIN="1", OMP_NUM_THREADS="4", **SWITCH_SETS[name])   # thinned shape lists: tests/test_gpu_ops.py
+        sel = "conv3x3_fwd_dgrad_wgrad or first_conv or conv_transpose or fused_bn_backward_statistics"
+        if name == "unfused_epilogues":
+            sel = "wgrad_tap_fused or conv3x3_fwd_dgrad_wgrad"
+        if name == "round1_kernels":
+            sel = "(" + sel + " or wgrad_tap_fused) and not f32"
+        cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_ops.py"), "-m", "gpu", "-x", "-q",
+               "-k", sel, "-p", "no:cacheprovider"]
+        procs[name] = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    for name, pr in procs.items():
+        out, _ = pr.communicate(timeout=900)
+        assert pr.returncode == 0, name + ":\n" + out[-3000:]
+        assert " passed" in out, name
 
 
 def test_train_step_under_unfused_switches_matches_default():
