@@ -219,20 +219,6 @@ int unetdc_bn_relu_bwd_frozen(const void* dskip, int ldskip, const void* dpool, 
                               const float* gamma, void* dy, int lddy, float* dgamma, float* dbeta, float* dbias,
                               void* workspace, int64_t workspace_bytes, const float* pre_parts, int pre_nparts, int n, int h,
                               int w, int c, int dtype, unetdc_stream_t s);
-/* Pooled encoder stage (its activation gradient = dskip + scatter of dpool to the window arg-max): the BatchNorm-backward
- * sums are linear in the gradient, so the dskip part may come from the epilogue of the kernel that wrote dskip --
- * unetdc_conv3x3_dgrad_bnstats on the [pixels, 2C] concat gradient with per-column constants that are neutral for the
- * up-sampled half (scale 0, shift 1, mean 0, rstd 0: gate always open, xhat 0, so that half's first sum is its plain column
- * sum = the ConvTranspose2d bias gradient, unetdc_parts_colsum) and this stage's for the skip half.  skip_parts:
- * [skip_rows][3][skip_row_channels] with this stage's columns from skip_c0 (64 spare rows behind them).  Only the dpool
- * part is reduced here (from y and dpool: dskip is read once, by the apply pass). */
-int unetdc_bn_relu_bwd_pool_split(const void* dskip, int ldskip, const void* dpool, int ldpool, const void* y, int ldy,
-                                  const float* scale, const float* shift, const float* mean, const float* rstd,
-                                  const float* gamma, void* dy, int lddy, float* dgamma, float* dbeta, float* dbias,
-                                  void* workspace, int64_t workspace_bytes, const float* skip_parts, int skip_rows,
-                                  int skip_row_channels, int skip_c0, int n, int h, int w, int c, int dtype, unetdc_stream_t s);
-/* out[i] = sum over rows of parts[row * row_floats + c0 + i], i < c (fp64 accumulation; 64 spare rows behind `rows`). */
-int unetdc_parts_colsum(const float* parts, int rows, int row_floats, int c0, int c, float* out, unetdc_stream_t s);
 /* dgrad fused with the BatchNorm-backward REDUCTION of the stage that consumes dx: besides dx the
  * kernel epilogue accumulates, per channel of dx, S1 = sum dx*[n>0] and S2 = sum dx*[n>0]*xhat with
  * n = scale*y_prev + shift, xhat = (y_prev - mean)*rstd (y_prev = that stage's saved conv output, same

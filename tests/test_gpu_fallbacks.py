@@ -45,9 +45,8 @@ def test_operator_parity_under_switches():
 
 
 def test_train_step_under_unfused_switches_matches_default():
-    """One bf16 training step at a small size: gradients with every fusion switched off, and with the opt-in split of the
-    pooled stages' BatchNorm-backward sums (UNETDC_FUSE_POOL_SKIP=1), == the default path within bf16 rounding (same
-    kernels' math, different launch structure); with only the round-3 backward fusions off (head-input gradient stored,
+    """One bf16 training step at a small size: gradients with every fusion switched off == the default path within bf16
+    rounding (same kernels' math, different launch structure); with only the round-3 backward fusions off (head-input gradient stored,
     first stage's BatchNorm backward as its own pass) == the default path bit for bit."""
     code = r'''
 import sys, torch
@@ -65,7 +64,7 @@ torch.save({k: p.grad.cpu() for k, p in m.named_parameters()}, sys.argv[1])
     # last arm: the per-tap kernels everywhere they can stand in (UNETDC_IGEMM=dma) -- the input-normalising forward of the
     # 64-channel blocks exists in the lattice kernel only and must still be the one that runs (a kernel that ignored in_scale
     # would feed the raw pre-BatchNorm tensor into the second convolution: cosine far below the bar)
-    arms = ({}, dict(SWITCH_SETS["unfused_epilogues"], UNETDC_FUSE_HEAD_BN="0"), {"UNETDC_FUSE_POOL_SKIP": "1"},
+    arms = ({}, dict(SWITCH_SETS["unfused_epilogues"], UNETDC_FUSE_HEAD_BN="0"),
             {"UNETDC_FUSE_HEAD_BWD": "0", "UNETDC_FUSE_FIRST_BN": "0"}, {"UNETDC_IGEMM": "dma"})
     for i, extra in enumerate(arms):
         path = os.path.join("/tmp", f"unetdc_fallback_grads_{os.getpid()}_{i}.pt")
@@ -76,8 +75,8 @@ torch.save({k: p.grad.cpu() for k, p in m.named_parameters()}, sys.argv[1])
         os.remove(path)
     # stored head-input gradient + two-pass BatchNorm backward of the first stage: the fused forms are BIT-identical
     for k in outs[0]:
-        assert torch.equal(outs[0][k], outs[3][k]), k
-    for other, bar in ((outs[1], 0.98), (outs[2], 0.98), (outs[4], 0.95)):    # (other convolution kernels: other summation orders)
+        assert torch.equal(outs[0][k], outs[2][k]), k
+    for other, bar in ((outs[1], 0.98), (outs[3], 0.95)):    # (other convolution kernels: other summation orders)
         for k in outs[0]:
             a, b = outs[0][k].double(), other[k].double()
             if k.endswith(".0.bias") or k.endswith(".3.bias"):

@@ -317,35 +317,6 @@ def test_bn_relu_fwd_bwd(dtype, pool, case):
     assert rel(dbet.cpu(), gb_ref) < tol, ("dbeta", rel(dbet.cpu(), gb_ref))
     assert rel(G.from_nhwc(dyv, n, h, w), gy_ref) < tol, ("dy", rel(G.from_nhwc(dyv, n, h, w), gy_ref))
     assert float(dbias.abs().max()) < 1e-2 * float(gb_ref.abs().max() + 1)     # ~0 by construction
-    if pool:
-        # ---- split form: the dskip part of the sums arrives as partial rows [rows][3][2c] (this stage's columns from c,
-        # as the epilogue of the dgrad that writes the [pixels, 2c] concat gradient leaves them), only the dpool part is
-        # reduced by the call.  The rows are built here from the device's own stored tensors, spread over 3 rows.
-        yq, dsq = yv.float().cpu()[:, :c].double(), dsv.float().cpu().double()
-        gate = (yq * scale.cpu().double() + shift.cpu().double()) > 0
-        xh = (yq - mean.cpu().double()) * rstd.cpu().double()
-        gh = torch.where(gate, dsq, torch.zeros_like(dsq))
-        rows = 3
-        sp = torch.zeros((rows + 64) * 3 * 2 * c, device="cuda")
-        spv = sp[: rows * 3 * 2 * c].view(rows, 3, 2 * c)
-        spv[:, :, :c] = 7.0                                   # the other half of the row: must not be read
-        for r in range(rows):
-            sel = slice(r, None, rows)
-            spv[r, 0, c:] = gh[sel].sum(0).float().cuda()
-            spv[r, 1, c:] = (gh[sel] * xh[sel]).sum(0).float().cuda()
-            spv[r, 2, c:] = 0.0
-        dy2 = G.empty_nhwc(cnt, c, dtype)
-        dgam2, dbet2, dbias2 = (torch.full((c,), float("nan"), **f32) for _ in range(3))
-        call("unetdc_bn_relu_bwd_pool_split", dsv.data_ptr(), dsv.stride(0), dpv.data_ptr(), dpv.stride(0), yv.data_ptr(),
-             yv.stride(0), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gd.data_ptr(),
-             dy2.data_ptr(), dy2.stride(0), dgam2.data_ptr(), dbet2.data_ptr(), dbias2.data_ptr(), ws.data_ptr(), nbytes,
-             sp.data_ptr(), rows, 2 * c, c, n, h, w, c, G.DT[dtype], G.stream())
-        assert rel(dgam2.cpu(), dgam.cpu()) < 2e-5 and rel(dbet2.cpu(), dbet.cpu()) < 2e-5
-        assert rel(G.from_nhwc(dy2, n, h, w), G.from_nhwc(dyv, n, h, w)) < (2e-5 if dtype == "f32" else 8e-3)
-        # column sums of partial rows (the ConvTranspose2d bias gradient out of the same rows)
-        cs = torch.full((c,), float("nan"), **f32)
-        call("unetdc_parts_colsum", sp.data_ptr(), rows, 3 * 2 * c, c, c, cs.data_ptr(), G.stream())
-        np.testing.assert_allclose(cs.cpu().numpy(), spv[:, 0, c:].double().sum(0).float().cpu().numpy(), rtol=1e-6)
 
 
 @pytest.mark.parametrize("rows,c", [(1, 64), (37, 6), (512, 64), (700, 10), (300, 1024)])

@@ -57,8 +57,6 @@ SIGNATURES = {
     "unetdc_bn_relu_bwd_coeffs": (I, [P, I, P, P, P, P, P, P, I, I, I, I, P]),
     "unetdc_conv3x3_first_wgrad_bn": (I, [P, P, I, P, I, P, P, P, P, P, P, P, L, I, I, I, I, I, I, I, P]),
     "unetdc_bn_relu_bwd_frozen": (I, [P, I, P, I, P, I, P, P, P, P, P, P, I, P, P, P, P, L, P, I, I, I, I, I, I, P]),
-    "unetdc_bn_relu_bwd_pool_split": (I, [P, I, P, I, P, I, P, P, P, P, P, P, I, P, P, P, P, L, P, I, I, I, I, I, I, I, I, P]),
-    "unetdc_parts_colsum": (I, [P, I, I, I, I, P, P]),
     "unetdc_conv3x3_dgrad_bnstats": (I, [P, I, P, P, I, P, I, P, P, P, P, P, L, P, I, I, I, I, I, I, I, P]),
     "unetdc_convT2x2_dgrad_bnstats": (I, [P, I, P, P, I, P, I, P, P, P, P, P, L, P, I, I, I, I, I, I, P]),
     "unetdc_head_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, P]),

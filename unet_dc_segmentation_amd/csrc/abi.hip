@@ -421,23 +421,6 @@ int unetdc_bn_relu_bwd_frozen(const void* dskip, int ldskip, const void* dpool, 
                        (hipStream_t)s, true);
 }
 
-int unetdc_bn_relu_bwd_pool_split(const void* dskip, int ldskip, const void* dpool, int ldpool, const void* y, int ldy,
-                                  const float* scale, const float* shift, const float* mean, const float* rstd,
-                                  const float* gamma, void* dy, int lddy, float* dgamma, float* dbeta, float* dbias,
-                                  void* workspace, int64_t workspace_bytes, const float* skip_parts, int skip_rows,
-                                  int skip_row_channels, int skip_c0, int n, int h, int w, int c, int dtype, unetdc_stream_t s) {
-  GEOM_CHECK(n, h, w);
-  BnBwdParams p{};
-  p.dskip = dskip; p.dpool = dpool; p.y = y; p.dy = dy; p.scale = scale; p.shift = shift; p.mean = mean; p.rstd = rstd;
-  p.N = n; p.H = h; p.W = w; p.C = c; p.lds = ldskip; p.ldp = ldpool; p.ldy = ldy; p.lddy = lddy;
-  return launch_bn_bwd_pool_split(p, gamma, dgamma, dbeta, dbias, workspace, (long)workspace_bytes, skip_parts, skip_rows,
-                                  skip_row_channels, skip_c0, dtype, (hipStream_t)s);
-}
-
-int unetdc_parts_colsum(const float* parts, int rows, int row_floats, int c0, int c, float* out, unetdc_stream_t s) {
-  return launch_stats_colsum_rows(parts, rows, row_floats, c0, c, out, (hipStream_t)s);
-}
-
 int unetdc_head_fwd(const void* a, int lda, const float* w, const float* b, float* probs, int n, int h, int wd,
                     int c, int oc, int dtype, unetdc_stream_t s) {
   GEOM_CHECK(n, h, wd);

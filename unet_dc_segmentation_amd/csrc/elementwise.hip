@@ -983,61 +983,6 @@ int launch_bn_bwd_coeffs(const float* pre_parts, int pre_nparts, long count, con
   return check_launch("bn_bwd_finalize_kernel");
 }
 
-// Pooled encoder stage whose gradient is  dskip + scatter(dpool):  the sums are linear in the gradient, so the dskip part
-// comes in as partial rows from the epilogue of the kernel that wrote dskip (skip_parts: [skip_rows][3][skip_cs], this
-// stage's columns from skip_c0) and only the dpool part (plus S3 = sum xhat) is reduced here, from y and dpool alone:
-// the reduction pass no longer reads dskip.  Then finalize over both row sets and the usual apply pass.
-int launch_bn_bwd_pool_split(BnBwdParams& p, const float* gamma, float* dgamma, float* dbeta, float* dbias, void* workspace,
-                             long workspace_bytes, const float* skip_parts, int skip_rows, int skip_cs, int skip_c0, int dtype,
-                             hipStream_t stream) {
-  const int epc = dtype == UNETDC_BF16 ? 8 : 4;
-  UNETDC_REQUIRE(dtype == UNETDC_F32 || dtype == UNETDC_BF16, "bn_bwd_pool_split: bad dtype %d", dtype);
-  UNETDC_REQUIRE(p.y && p.dy && p.dskip && p.dpool, "bn_bwd_pool_split: null tensor");
-  UNETDC_REQUIRE(p.scale && p.shift && p.mean && p.rstd && gamma && dgamma && dbeta && workspace && skip_parts,
-                 "bn_bwd_pool_split: null pointer");
-  UNETDC_REQUIRE(p.C % epc == 0 && p.ldy % epc == 0 && p.lddy % epc == 0 && p.lds % epc == 0 && p.ldp % epc == 0,
-                 "bn_bwd_pool_split: C/ld not chunk aligned");
-  UNETDC_REQUIRE(p.H % 2 == 0 && p.W % 2 == 0, "bn_bwd_pool_split: pooling needs even H, W");
-  UNETDC_REQUIRE(skip_rows > 0 && skip_cs >= skip_c0 + p.C && skip_c0 >= 0, "bn_bwd_pool_split: bad partial-row geometry");
-  const int cpp = p.C / epc;
-  const int seg = cpp < 256 ? cpp : 256;
-  UNETDC_REQUIRE(256 % seg == 0, "bn_bwd_pool_split: C=%d unsupported", p.C);
-  const long Q = (long)p.N * (p.H / 2) * (p.W / 2);
-  const int nb = bn_bwd_blocks(Q, cpp);
-  const long need = ((long)(nb + 64) * 3 * p.C + 3 * p.C) * 4;
-  if (need > workspace_bytes) {
-    set_error("bn_bwd_pool_split: workspace too small (%ld < %ld bytes)", workspace_bytes, need);
-    return UNETDC_EWORKSPACE;
-  }
-  float* ws = reinterpret_cast<float*>(workspace);
-  float* k = ws;
-  float* parts = ws + 3 * p.C;
-  p.parts = parts;
-  p.k1 = k; p.k2 = k + p.C; p.k3 = k + 2 * p.C;
-  const dim3 grid(nb, (cpp + seg - 1) / seg);
-  BnBwdParams pr = p;
-  pr.dskip = nullptr;                                    // pooled part only: g = scatter(dpool)
-  if (dtype == UNETDC_BF16) launch_bn_bwd_k<bf16_t>(pr, true, false, grid, stream);
-  else launch_bn_bwd_k<float>(pr, true, false, grid, stream);
-  int rc = check_launch("bn_bwd_kernel(reduce, pooled part)");
-  if (rc != UNETDC_OK) return rc;
-  const float* rp; int rows;
-  rc = reduce_parts(parts, nb, 3 * p.C, &rp, &rows, stream, 512);
-  if (rc != UNETDC_OK) return rc;
-  const float* sp; int srows;
-  rc = reduce_parts(skip_parts, skip_rows, 3 * skip_cs, &sp, &srows, stream, 512);    // > 512 rows: one stage into the 64 spare rows
-  if (rc != UNETDC_OK) return rc;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((p.C + FIN_C - 1) / FIN_C), dim3(256), 0, stream, sp, srows, skip_cs, skip_c0, rp, rows,
-                     (double)p.N * p.H * p.W, gamma, p.rstd, dgamma, dbeta, dbias, k, k + p.C, k + 2 * p.C, p.C, 0);
-  rc = check_launch("bn_bwd_finalize_kernel");
-  if (rc != UNETDC_OK) return rc;
-  const long items = Q * cpp;
-  const dim3 grid2(grid_for(items, 256) > 4096 ? 4096 : grid_for(items, 256), (cpp + seg - 1) / seg);
-  if (dtype == UNETDC_BF16) launch_bn_bwd_k<bf16_t>(p, true, true, grid2, stream);
-  else launch_bn_bwd_k<float>(p, true, true, grid2, stream);
-  return check_launch("bn_bwd_kernel(apply)");
-}
-
 static int head_blocks(long P, int cpp) {
   long nb = (P + (256 / cpp) * 8 - 1) / ((256 / cpp) * 8);
   if (nb > 1024) nb = 1024;

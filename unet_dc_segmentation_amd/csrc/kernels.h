@@ -140,9 +140,6 @@ int launch_bn_bwd(BnBwdParams& p, const float* gamma, float* dgamma, float* dbet
                   bool frozen = false);
 int launch_bn_frozen_affine(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* scale,
                             float* shift, float* mean, float* rstd, int C, hipStream_t stream);
-int launch_bn_bwd_pool_split(BnBwdParams& p, const float* gamma, float* dgamma, float* dbeta, float* dbias, void* workspace,
-                             long workspace_bytes, const float* skip_parts, int skip_rows, int skip_cs, int skip_c0, int dtype,
-                             hipStream_t stream);
 int launch_stats_colsum_rows(const float* parts, int nparts, int row_floats, int c0, int c, float* out, hipStream_t stream);
 int launch_bn_bwd_reduce_only(BnBwdParams& p, float* parts, long parts_floats, int* nparts, int dtype,
                               hipStream_t stream);

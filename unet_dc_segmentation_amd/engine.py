@@ -35,13 +35,6 @@ ENCODER = ("enc1", "enc2", "enc3", "enc4")
 FUSE_BN_BWD = os.environ.get("UNETDC_FUSE_BNBWD", "1") != "0"
 # ConvTranspose2d bias gradient = column sums of the concat gradient, produced by the dgrad epilogue that writes it
 FUSE_COLSUM = os.environ.get("UNETDC_FUSE_COLSUM", "1") != "0"
-# Pooled encoder stages (gradient = skip half of the concat gradient + scatter of the pooled gradient): the skip part of their
-# BatchNorm-backward sums rides in the epilogue of the decoder dgrad that writes the concat gradient (unetdc_conv3x3_dgrad_bnstats
-# with per-column constants that are neutral for the up-sampled half), so the stage's own reduction pass reads only y and
-# dpool (unetdc_bn_relu_bwd_pool_split).  Opt-in (UNETDC_FUSE_POOL_SKIP=1): measured on MI355X the BatchNorm passes get
-# 0.08 ms cheaper per step and the four decoder dgrads 0.06 + 0.03 ms dearer (their epilogue now also reads the encoder's
-# saved outputs): no net gain, so the default keeps the two-pass form over dskip + dpool.
-FUSE_POOL_SKIP = os.environ.get("UNETDC_FUSE_POOL_SKIP", "0") == "1" and FUSE_COLSUM and FUSE_BN_BWD
 # The head reads dec1's RAW conv output and applies that stage's BatchNorm + ReLU on load (unetdc_head_fwd_bn; the backward
 # recomputes the activation the same way): dec1.3's normalisation pass and its 268 MB activation tensor disappear from the
 # training step.  UNETDC_FUSE_HEAD_BN=0: stand-alone pass (A/B switch)
@@ -51,14 +44,6 @@ FUSE_HEAD_BN = os.environ.get("UNETDC_FUSE_HEAD_BN", "1") != "0" and FUSE_BN_BWD
 # that stage's normalisation pass and activation tensor disappear.  Used where the library has the kernels (bf16, 64-channel
 # blocks: enc1 and dec1, the two largest normalisation passes of the step).  UNETDC_FUSE_BNIN=0: stand-alone passes (A/B)
 FUSE_BNIN = os.environ.get("UNETDC_FUSE_BNIN", "1") != "0"
-# Opt-in (UNETDC_SIDE_WGRAD=1): run the weight-gradient kernels, which hang off the backward critical chain, on a side
-# HIP stream.  Measured on MI355X in round 3 (same-box A/B, profiles/r03_side_stream_ab.txt): +1.3 ... +2.2 % with the 32x32x16
-# weight gradient, within noise since it moved to 16x16x32 MFMAs (11.41 vs 11.36 / 11.49 ms per step).  What overlapped was
-# the tail of a stage's dgrad, NOT the HBM-bound BatchNorm passes: both MFMA kernel families hold the whole register file
-# (2 x 234-246 registers per SIMD lane), so a BatchNorm wave finds no room beside them; limiting the weight gradient to one
-# workgroup per CU, or starting it only behind its stage's dgrad, lost more than the overlap gave.  Off by default also
-# because overlapping kernels make per-kernel timings unattributable (bench.py's roofline leg then reads 0.38 instead of
-# 0.49 for the dominant kernel).
 # One-channel head (the networks' configuration): the gradient of the head's input is dz * w[c] per pixel, so dec1's last stage
 # recomputes it in its BatchNorm-backward pass (unetdc_bn_relu_bwd_head) instead of reading a tensor the head backward wrote:
 # 2 x 268 MB less traffic per step at 8 x 512 x 512, bit-identical.  UNETDC_FUSE_HEAD_BWD=0: stored form (A/B).
@@ -67,7 +52,6 @@ FUSE_HEAD_BWD = os.environ.get("UNETDC_FUSE_HEAD_BWD", "1") == "1"
 # (unetdc_conv3x3_first_wgrad_bn) -- nothing else reads that stage's dy unless dL/dx is asked for, so the pass that writes it
 # (3 x 268 MB of traffic at 8 x 512 x 512) is not run.  Bit-identical.  UNETDC_FUSE_FIRST_BN=0: two-pass form (A/B).
 FUSE_FIRST_BN = os.environ.get("UNETDC_FUSE_FIRST_BN", "1") == "1"
-SIDE_WGRAD = os.environ.get("UNETDC_SIDE_WGRAD", "0") == "1"
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
@@ -195,8 +179,7 @@ class _Stage:
         self.bwd_rows = _lib.load().unetdc_conv3x3_stats_rows(npix, cout)
         self.bwd_parts = None
         self.bwd_nparts = 0
-        self.dy = None        # gradient of this stage's conv output (own buffer: read by dgrad on the main
-        #                       stream and by wgrad on the side stream)
+        self.dy = None        # gradient of this stage's conv output
 
 
 class UNetEngine:
@@ -247,21 +230,6 @@ class UNetEngine:
             name = f"dec{lvl}"
             self.stages[(name, 0)] = _Stage(self, name, 0, 2 * c, c, d[name], self.npix[lvl - 1], self.res[lvl - 1])
             self.stages[(name, 3)] = _Stage(self, name, 3, c, c, d[name], self.npix[lvl - 1], self.res[lvl - 1])
-        # pooled encoder stages: per level the four per-channel constant arrays of the stage are the SECOND halves of
-        # [2C] arrays whose first halves are neutral (scale 0, shift 1, mean 0, rstd 0); the saved conv output has one spare
-        # pixel row in front (the fused epilogue addresses column C + c of the concat gradient as y[pixel][c] through a
-        # base pointer C elements early; the up-sampled half then reads the previous pixel's row: any finite value will do)
-        self.combo = {}
-        for l, name in enumerate(ENCODER):
-            st = self.stages[(name, 3)]
-            c = st.cout
-            combo = torch.zeros(4, 2 * c, device=dev, dtype=torch.float32)
-            combo[1, :c] = 1.0
-            st.scale, st.shift, st.mean, st.rstd = combo[0, c:], combo[1, c:], combo[2, c:], combo[3, c:]
-            ybuf = torch.zeros((st.npix + 1) * c, device=dev, dtype=dt)
-            st.y = ybuf[c:].view(st.npix, c)
-            st.skip_parts, st.skip_rows = None, 0
-            self.combo[l + 1] = combo
         # activations
         self.a0 = {}      # activated output of stage 0 of each block
         self.a3 = {}      # activated output of stage 3 for bottleneck / decoder blocks
@@ -475,28 +443,6 @@ class UNetEngine:
             st.dy = torch.empty(st.npix, st.cout, device=dev, dtype=dt)
         self.grad_bufs = g
         self.workspace = torch.empty(self.ws_bytes, device=dev, dtype=torch.uint8)
-        self.side = torch.cuda.Stream(device=dev) if SIDE_WGRAD else None
-        self.ws_side = torch.empty(self.ws_bytes, device=dev, dtype=torch.uint8) if SIDE_WGRAD else self.workspace
-
-    def _side_after_main(self):
-        """Context: (stream handle, workspace pointer) for work that may leave the critical chain.
-        The side stream first waits for everything enqueued on the main stream so far."""
-        import contextlib
-
-        @contextlib.contextmanager
-        def ctx():
-            if self.side is None:
-                yield _stream(), self.workspace.data_ptr()
-                return
-            ev = torch.cuda.Event()
-            ev.record()                                   # main (current) stream
-            self.side.wait_event(ev)
-            yield self.side.cuda_stream, self.ws_side.data_ptr()
-        return ctx()
-
-    def _join_side(self):
-        if self.side is not None:
-            torch.cuda.current_stream().wait_stream(self.side)
 
     def _gview(self, flat, p):
         i = self.pindex[id(p)]
@@ -511,7 +457,7 @@ class UNetEngine:
                 prev.mean.data_ptr(), prev.rstd.data_ptr(), prev.bwd_parts.data_ptr(), prev.bwd_parts.numel(),
                 __import__("ctypes").byref(self._np))
 
-    def _stage_bwd(self, st, flat, lvl, dskip, dpool, dx_out, fuse_prev=None, colsum=None, skip_for=None, head=None):
+    def _stage_bwd(self, st, flat, lvl, dskip, dpool, dx_out, fuse_prev=None, colsum=None, head=None):
         """Backward of one stage.  dskip/dpool: incoming gradient(s) of the activation;
         dx_out: [npix, cin] view to receive the input gradient (None for the first stage);
         fuse_prev: the stage consuming dx_out as its activation gradient -- its BatchNorm-backward
@@ -524,17 +470,8 @@ class UNetEngine:
         dy = st.dy
         ws, wsb = self.workspace.data_ptr(), self.ws_bytes
         pre = (st.bwd_parts.data_ptr(), st.bwd_nparts) if (st.bwd_nparts and dpool is None) else (None, 0)
-        if dpool is not None and dskip is not None and getattr(st, "skip_rows", 0) and not self._frozen:
-            # the skip part of the sums came out of the decoder dgrad that wrote dskip (see FUSE_POOL_SKIP)
-            call("unetdc_bn_relu_bwd_pool_split", dskip.data_ptr(), dskip.stride(0), dpool.data_ptr(), dpool.stride(0),
-                 st.y.data_ptr(), st.y.stride(0), st.scale.data_ptr(), st.shift.data_ptr(), st.mean.data_ptr(),
-                 st.rstd.data_ptr(), st.bn.weight.data_ptr(), dy.data_ptr(), dy.stride(0),
-                 self._gview(flat, st.bn.weight).data_ptr(), self._gview(flat, st.bn.bias).data_ptr(),
-                 self._gview(flat, st.conv.bias).data_ptr(), ws, wsb, st.skip_parts.data_ptr(), st.skip_rows,
-                 2 * st.cout, st.cout, N, h, w, st.cout, self.dt, s)
-            st.skip_rows = 0
-        elif (st.first and FUSE_FIRST_BN and pre[0] is not None and dskip is not None and not self._frozen
-              and not getattr(self, "_need_dx", False) and self.side is None
+        if (st.first and FUSE_FIRST_BN and pre[0] is not None and dskip is not None and not self._frozen
+              and not getattr(self, "_need_dx", False)
               and _lib.load().unetdc_conv3x3_first_wgrad_bn_supported(N, h, w, st.cin, st.cout, st.dil, self.dt)):
             # BatchNorm backward of the first stage on load of its weight gradient: dy is never written
             if getattr(st, "bwd_coeffs", None) is None:
@@ -558,7 +495,7 @@ class UNetEngine:
         else:
             self._bn_relu_bwd_plain(st, flat, dskip, dpool, dy, pre, ws, wsb, N, h, w, s)
         st.bwd_nparts = 0
-        self._stage_bwd_rest(st, flat, lvl, dx_out, fuse_prev, colsum, skip_for, dy, ws, wsb, N, h, w, s)
+        self._stage_bwd_rest(st, flat, lvl, dx_out, fuse_prev, colsum, dy, ws, wsb, N, h, w, s)
 
     def _bn_relu_bwd_plain(self, st, flat, dskip, dpool, dy, pre, ws, wsb, N, h, w, s):
         call("unetdc_bn_relu_bwd_frozen" if self._frozen and st.bn.running_mean is not None else "unetdc_bn_relu_bwd", _ptr(dskip), dskip.stride(0) if dskip is not None else 0,
@@ -568,51 +505,33 @@ class UNetEngine:
              self._gview(flat, st.bn.bias).data_ptr(), self._gview(flat, st.conv.bias).data_ptr(), ws, wsb,
              pre[0], pre[1], N, h, w, st.cout, self.dt, s)
 
-    def _stage_bwd_rest(self, st, flat, lvl, dx_out, fuse_prev, colsum, skip_for, dy, ws, wsb, N, h, w, s):
+    def _stage_bwd_rest(self, st, flat, lvl, dx_out, fuse_prev, colsum, dy, ws, wsb, N, h, w, s):
         dw = self._gview(flat, st.conv.weight)
         xin = st.x_in
 
         def wgrad():
-            with self._side_after_main() as (s2, ws2):
-                if st.first:
-                    call("unetdc_conv3x3_first_wgrad", xin.data_ptr(), dy.data_ptr(), dy.stride(0), dw.data_ptr(), ws2, wsb,
-                         N, h, w, st.cin, st.cout, st.dil, self.dt, s2)
-                elif st.bnin is not None:
-                    call("unetdc_conv3x3_wgrad_bnin", xin.data_ptr(), xin.stride(0), st.bnin[0].data_ptr(),
-                         st.bnin[1].data_ptr(), dy.data_ptr(), dy.stride(0), dw.data_ptr(), ws2, wsb, N, h, w, st.cin,
-                         st.cout, st.dil, self.dt, s2)
-                else:
-                    call("unetdc_conv3x3_wgrad", xin.data_ptr(), xin.stride(0), dy.data_ptr(), dy.stride(0), dw.data_ptr(),
-                         ws2, wsb, N, h, w, st.cin, st.cout, st.dil, self.dt, s2)
+            s2, ws2 = s, ws
+            if st.first:
+                call("unetdc_conv3x3_first_wgrad", xin.data_ptr(), dy.data_ptr(), dy.stride(0), dw.data_ptr(), ws2, wsb,
+                     N, h, w, st.cin, st.cout, st.dil, self.dt, s2)
+            elif st.bnin is not None:
+                call("unetdc_conv3x3_wgrad_bnin", xin.data_ptr(), xin.stride(0), st.bnin[0].data_ptr(),
+                     st.bnin[1].data_ptr(), dy.data_ptr(), dy.stride(0), dw.data_ptr(), ws2, wsb, N, h, w, st.cin,
+                     st.cout, st.dil, self.dt, s2)
+            else:
+                call("unetdc_conv3x3_wgrad", xin.data_ptr(), xin.stride(0), dy.data_ptr(), dy.stride(0), dw.data_ptr(),
+                     ws2, wsb, N, h, w, st.cin, st.cout, st.dil, self.dt, s2)
 
         wgrad()
-        self._stage_dgrad(st, dx_out, fuse_prev, colsum, skip_for, dy, ws, wsb, N, h, w, s)
+        self._stage_dgrad(st, dx_out, fuse_prev, colsum, dy, ws, wsb, N, h, w, s)
 
-    def _stage_dgrad(self, st, dx_out, fuse_prev, colsum, skip_for, dy, ws, wsb, N, h, w, s):
+    def _stage_dgrad(self, st, dx_out, fuse_prev, colsum, dy, ws, wsb, N, h, w, s):
         if not st.first:
             if dx_out is not None and fuse_prev is not None and FUSE_BN_BWD:
                 call("unetdc_conv3x3_dgrad_bnstats", dy.data_ptr(), dy.stride(0), st.w_dgrad.data_ptr(),
                      dx_out.data_ptr(), dx_out.stride(0), *self._bnstats_args(fuse_prev), N, h, w, st.cin, st.cout,
                      st.dil, self.dt, s)
                 fuse_prev.bwd_nparts = self._np.value
-            elif dx_out is not None and colsum is not None and skip_for is not None and FUSE_POOL_SKIP and not self._frozen:
-                # dx_out = gradient of cat([up, skip]): one epilogue gives the column sums of its first half (the up-conv
-                # bias gradient) AND the skip part of the encoder stage's BatchNorm-backward sums
-                enc, combo = skip_for
-                c = enc.cout
-                if enc.skip_parts is None:
-                    rows = _lib.load().unetdc_conv3x3_stats_rows(st.npix, 2 * c)
-                    enc.skip_parts = torch.empty((rows + 64) * 3 * 2 * c, device=self.device, dtype=torch.float32)
-                self._np = getattr(self, "_np", None) or __import__("ctypes").c_int(0)
-                es = 2 if self.dt == _lib.BF16 else 4
-                call("unetdc_conv3x3_dgrad_bnstats", dy.data_ptr(), dy.stride(0), st.w_dgrad.data_ptr(),
-                     dx_out.data_ptr(), dx_out.stride(0), enc.y.data_ptr() - c * es, c, combo[0].data_ptr(),
-                     combo[1].data_ptr(), combo[2].data_ptr(), combo[3].data_ptr(), enc.skip_parts.data_ptr(),
-                     enc.skip_parts.numel(), __import__("ctypes").byref(self._np), N, h, w, st.cin, st.cout, st.dil,
-                     self.dt, s)
-                enc.skip_rows = self._np.value
-                call("unetdc_parts_colsum", enc.skip_parts.data_ptr(), enc.skip_rows, 3 * 2 * c, colsum[1], colsum[2],
-                     colsum[0].data_ptr(), s)
             elif dx_out is not None and colsum is not None and FUSE_COLSUM:
                 call("unetdc_conv3x3_dgrad_colsum", dy.data_ptr(), dy.stride(0), st.w_dgrad.data_ptr(), dx_out.data_ptr(),
                      dx_out.stride(0), colsum[0].data_ptr(), colsum[1], colsum[2], ws, wsb, N, h, w, st.cin, st.cout,
@@ -621,20 +540,19 @@ class UNetEngine:
                 call("unetdc_conv3x3_dgrad", dy.data_ptr(), dy.stride(0), st.w_dgrad.data_ptr(), dx_out.data_ptr(),
                      dx_out.stride(0), N, h, w, st.cin, st.cout, st.dil, self.dt, s)
 
-    def _block_bwd(self, name, flat, lvl, dskip, dpool, dx_out, colsum=None, skip_for=None, head=None):
+    def _block_bwd(self, name, flat, lvl, dskip, dpool, dx_out, colsum=None, head=None):
         """stage 3 then stage 0 of a block; the gradient between them lives in the 'da' buffer."""
         da = self.grad_bufs[("da", lvl)]
         s3, s0 = self.stages[(name, 3)], self.stages[(name, 0)]
         self._stage_bwd(s3, flat, lvl, dskip, dpool, da, fuse_prev=s0, head=head)
         self._notify(flat, [s3.conv, s3.bn])             # per STAGE: bottleneck.3's 37.7 MB travel while bottleneck.0 computes
-        self._stage_bwd(s0, flat, lvl, da, None, dx_out, colsum=colsum, skip_for=skip_for)
+        self._stage_bwd(s0, flat, lvl, da, None, dx_out, colsum=colsum)
         self._notify(flat, [s0.conv, s0.bn])
 
     def _notify(self, flat, mods):
         """Tell the data-parallel wrapper that the gradients of `mods` (adjacent in parameters() order) are enqueued."""
         hook = self.model.grad_ready_hook
         if hook is not None:
-            self._join_side()                            # the weight gradients may run on the side stream
             ps = [q for m in mods for q in m.parameters()]
             lo = self.poffs[self.pindex[id(ps[0])]]
             hi = self.poffs[self.pindex[id(ps[-1])]] + ps[-1].numel()
@@ -688,16 +606,15 @@ class UNetEngine:
             dcat = g[("dcat", lvl)]
             # the dgrad that writes dcat = grad of cat([up, enc]) also sums its first half per channel = upconv bias grad
             self._block_bwd(f"dec{lvl}", flat, l, dact, None, dcat, colsum=(self._gview(flat, u["mod"].bias), 0, c),
-                            skip_for=(self.stages[(ENCODER[l], 3)], self.combo[lvl]), head=head if lvl == 1 else None)
+                            head=head if lvl == 1 else None)
             dup = dcat[:, :c]
             h, w = self.res[lvl]
             xin = u["x_in"]
-            with self._side_after_main() as (s2, ws2):
-                call("unetdc_convT2x2_wgrad", xin.data_ptr(), xin.stride(0), dup.data_ptr(), dup.stride(0),
-                     self._gview(flat, u["mod"].weight).data_ptr(), ws2, wsb, N, h, w, u["cin"], c, self.dt, s2)
-                if not FUSE_COLSUM:
-                    call("unetdc_channel_sum", dup.data_ptr(), dup.stride(0), self._gview(flat, u["mod"].bias).data_ptr(),
-                         ws2, wsb, self.npix[l], c, self.dt, s2)
+            call("unetdc_convT2x2_wgrad", xin.data_ptr(), xin.stride(0), dup.data_ptr(), dup.stride(0),
+                 self._gview(flat, u["mod"].weight).data_ptr(), ws, wsb, N, h, w, u["cin"], c, self.dt, s)
+            if not FUSE_COLSUM:
+                call("unetdc_channel_sum", dup.data_ptr(), dup.stride(0), self._gview(flat, u["mod"].bias).data_ptr(),
+                     ws, wsb, self.npix[l], c, self.dt, s)
             dnext = g[("da", lvl)]               # gradient w.r.t. the up-conv input (level lvl+1 resolution)
             prev = self.stages[("bottleneck" if lvl == 4 else f"dec{lvl + 1}", 3)]     # producer of the up-conv input
             if FUSE_BN_BWD:
@@ -719,9 +636,6 @@ class UNetEngine:
             dskip = g[("dcat", lvl)][:, c:]
             dx_out = g[("dpool", lvl - 1)] if lvl > 1 else None
             self._block_bwd(name, flat, l, dskip, g[("dpool", lvl)], dx_out)
-        if self.side is not None:
-            flat.record_stream(self.side)
-        self._join_side()
         return flat
 
 
