@@ -218,7 +218,9 @@ def test_first_conv(dtype, cin, shape):
 @pytest.mark.parametrize("case", [(2, 8, 12, 128, 64), (1, 16, 16, 256, 128), (1, 4, 4, 1024, 512),
                                   # W % 32 == 0: the tap-fused weight gradient (convt_wgrad.hip, bf16): one / several channel tiles,
                                   # several K slices, rows of 32 / 64 / 96 pixels, two images
-                                  (2, 32, 32, 256, 128), (1, 64, 64, 128, 64), (2, 16, 96, 512, 256), (1, 32, 32, 1024, 512)])
+                                  (2, 32, 32, 256, 128), (1, 64, 64, 128, 64), (2, 16, 96, 512, 256), (1, 32, 32, 1024, 512),
+                                  # the shortest K range the plan accepts (two 32-pixel steps per half); a half that crosses an image
+                                  (1, 4, 32, 128, 64), (3, 8, 32, 128, 64)])
 def test_conv_transpose(dtype, case):
     n, h, w, cin, cout = case
     g = gen(7)
