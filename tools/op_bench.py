@@ -86,6 +86,14 @@ def run():
 for _ in range(3):
     run()
 torch.cuda.synchronize()
+# steady state: the first milliseconds after idle run at a lower clock (the same launch reads 131.7 us in a cold 30-launch loop and
+# 111.9 us after 2 s of back-to-back launches, profiles/r04_power_probes.txt; MI355X_MICROARCH.md, DVFS item 6)
+import time
+_t0 = time.perf_counter()
+while time.perf_counter() - _t0 < float(os.environ.get("OPB_WARM_S", "1.5")):
+    for _ in range(50):
+        run()
+    torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(reps):

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Does the chip lend the power an HBM-bound kernel leaves unused to the MFMA kernel next to it in time?
+
+    python tools/power_interleave_probe.py [seconds of warm loop, default 2]
+
+Times ONE convolution launch (512 -> 512 @ 64 x 64, bs 8, bf16, random operands: the wide lattice kernel) by HIP events
+  A  in a loop of nothing but that launch,
+  B  alternating with a 268 MB device copy (HBM bound, no matrix work), as the BatchNorm passes alternate with the convolutions
+     in a training step,
+  C  alternating with an idle gap of about the copy's duration (torch.cuda._sleep),
+each after `seconds` of the same loop (MI355X_MICROARCH.md, DVFS item 6: steady state needs >= 2 s of back-to-back launches).
+"""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tests import gpu_ops as G
+
+warm_s = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
+n, h, w, cin, cout, d, dtype = 8, 64, 64, 512, 512, 1, "bf16"
+g = torch.Generator().manual_seed(0)
+x = torch.randn(n * h * w, cin, generator=g).to(G.TD[dtype]).cuda()
+wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+wf, wd = G.pack_conv(wt, dtype)
+y = torch.empty(n * h * w, cout, dtype=G.TD[dtype], device="cuda")
+bias = torch.zeros(cout, device="cuda")
+src = torch.randn(8 * 512 * 512 * 64 // 2, device="cuda")          # 268 MB of fp32
+dst = torch.empty_like(src)
+
+
+def conv():
+    G.conv3x3_fwd(x, wf, bias, n, h, w, cin, cout, d, dtype, y, stats=True)
+
+
+def measure(other, label):
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < warm_s:
+        for _ in range(50):
+            conv()
+            other()
+        torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
+    for a, b in ev:
+        a.record()
+        conv()
+        b.record()
+        other()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
+    fl = 2.0 * n * h * w * cin * cout * 9
+    med = ts[len(ts) // 2]
+    print(f"{label:44s} conv median {med:7.1f} us  p10 {ts[20]:7.1f}  p90 {ts[180]:7.1f}   {fl / med / 1e6:7.1f} TFLOP/s", flush=True)
+
+
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); dst.copy_(src); e1.record(); torch.cuda.synchronize()
+e0.record(); dst.copy_(src); e1.record(); torch.cuda.synchronize()
+copy_us = e0.elapsed_time(e1) * 1e3
+print(f"268 MB copy: {copy_us:.1f} us")
+cycles = int(copy_us * 100)                                          # torch.cuda._sleep counts ~100 MHz-ish ticks: calibrated below
+e0.record(); torch.cuda._sleep(cycles); e1.record(); torch.cuda.synchronize()
+per = e0.elapsed_time(e1) * 1e3 / cycles
+cycles = max(1, int(copy_us / per))
+measure(lambda: None, "A  convolution only")
+measure(lambda: dst.copy_(src), "B  convolution, 268 MB copy, convolution, ...")
+measure(lambda: torch.cuda._sleep(cycles), "C  convolution, idle gap of the same length, ...")
+measure(lambda: None, "A  convolution only (again)")
