@@ -39,6 +39,17 @@ struct WgradFusedParams {
   const float* in_shift;
 };
 
+#ifdef UNETDC_WGRAD_STAMPS
+// DIAGNOSTIC BUILD ONLY (tools/probes/wgrad_stamps.sh; never part of libunetdc_hip.so): per wave, the shader-clock cycles of a
+// step spent (0) in the counted vmcnt wait, (1) at the workgroup barrier, (2) from the barrier to the first MFMA (first fragment
+// reads + DMA issue), (3) in the item loop, summed over the steps; [4] = steps.  Written once at the end, read by nothing.
+__device__ unsigned long long g_wgrad_stamps[512][8][5];
+extern "C" int unetdc_dbg_wgrad_stamps(unsigned long long* dst) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wgrad_stamps), sizeof(g_wgrad_stamps));
+}
+#define STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
+
 template <typename T> struct FusedCfg;
 template <> struct FusedCfg<bf16_t> { static constexpr int SEG = 64; };
 template <> struct FusedCfg<float> { static constexpr int SEG = 32; };
@@ -681,6 +692,10 @@ __device__ __forceinline__ void ring_split_body(const WgradFusedParams& p) {
     }
   };
 
+#ifdef UNETDC_WGRAD_STAMPS
+  unsigned long long st_sum[5] = {0, 0, 0, 0, 0}, st_t2 = 0;
+  const unsigned long long st_kernel0 = __builtin_amdgcn_s_memtime();
+#endif
   for (int img = 0; img < ipu && n0 + img < p.N; ++img) {
   n = n0 + img;
   if (img > 0) raw_barrier();                            // the previous image's last fragments have been read by every wave
@@ -697,13 +712,23 @@ __device__ __forceinline__ void ring_split_body(const WgradFusedParams& p) {
   }
   int sl0 = 0, sl1 = d, sl2 = 2 * d, sdy = 0;
   for (int s = 0; s < nsteps; ++s) {
+#ifdef UNETDC_WGRAD_STAMPS
+    STAMP(t0);
+#endif
     if (PF == 2 && s + 1 < nsteps) {                     // the group of step s+1 may stay in flight (in-order retirement)
       if (five) wait_vmcnt<NQ>();
       else wait_vmcnt<NQ - 1>();
     } else {
       wait_vmcnt<0>();
     }
+#ifdef UNETDC_WGRAD_STAMPS
+    STAMP(t1);
+#endif
     raw_barrier();
+#ifdef UNETDC_WGRAD_STAMPS
+    STAMP(t2);
+    st_sum[0] += t1 - t0; st_sum[1] += t2 - t1; st_t2 = t2;
+#endif
     if (INORM) {
       // the X rows that have landed with this step and were not normalised yet: at the first step of an image the 2d rows
       // issued up front and the row of group 0, afterwards the one new row y + d (ring slot sl2)
@@ -730,12 +755,26 @@ __device__ __forceinline__ void ring_split_body(const WgradFusedParams& p) {
     } else {
       split_step<TG>(acc, sdyp, xring + sl0 * XB, xring + sl1 * XB, xring + sl2 * XB, lane, qj, d, offs, issue_row);
     }
+#ifdef UNETDC_WGRAD_STAMPS
+    {
+      STAMP(t4);
+      st_sum[3] += t4 - st_t2;                            // barrier -> end of the step (first reads + items)
+      st_sum[4] += 1;
+    }
+#endif
     sl0 = (sl0 + 1 == R) ? 0 : sl0 + 1;
     sl1 = (sl1 + 1 == R) ? 0 : sl1 + 1;
     sl2 = (sl2 + 1 == R) ? 0 : sl2 + 1;
     sdy = (sdy + 1 == NDY) ? 0 : sdy + 1;
   }
   }                                                      // images of this unit
+#ifdef UNETDC_WGRAD_STAMPS
+  if (lane == 0 && blockIdx.x < 512) {
+    unsigned long long* o = g_wgrad_stamps[blockIdx.x][half * 4 + wave];
+    o[0] = st_sum[0]; o[1] = st_sum[1]; o[2] = st_kernel0; o[3] = st_sum[3]; o[4] = st_sum[4];
+    o[2] = __builtin_amdgcn_s_memtime() - st_kernel0;     // loop time incl. prologue (before the exchange / slab stores)
+  }
+#endif
 
   // every DMA has landed (vmcnt(0) on the last step); join of tap 4, (paired form) of the two halves, and the slab stores
   split_finish<HV>(acc, smem, smem_all, half, p, unit, i0, j0, qj, tg, lane);
