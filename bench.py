@@ -564,9 +564,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     final_loss = float(loss.item())
-    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    raw_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    step_ms = sorted(raw_ms)
     pct = lambda q: step_ms[min(len(step_ms) - 1, max(0, int(round(q * (len(step_ms) - 1)))))]   # noqa: E731
-    step_stats = {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "min": step_ms[0], "max": step_ms[-1], "n": len(step_ms),
+    step_stats = {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "min": step_ms[0], "max": step_ms[-1], "max_at_step": raw_ms.index(step_ms[-1]),
+                  "n": len(step_ms),
                   "measured": "HIP events on the launch stream at the step boundaries of the timed region (rank 0)"}
     hbm = hbm_leg(step, 2 if args.dtype == "bf16" else 4) if args.mode == "train" else None
 
