@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Does the chip lend the power an HBM-bound kernel leaves unused to the MFMA kernel next to it in time?
 
-    python tools/power_interleave_probe.py [seconds of warm loop, default 2]
+    python tools/probes/power_interleave_probe.py [seconds of warm loop, default 2]
 
 Times ONE convolution launch (512 -> 512 @ 64 x 64, bs 8, bf16, random operands: the wide lattice kernel) by HIP events
   A  in a loop of nothing but that launch,
@@ -13,7 +13,7 @@ each after `seconds` of the same loop (MI355X_MICROARCH.md, DVFS item 6: steady 
 import os
 import sys
 import time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from tests import gpu_ops as G
 
