@@ -504,7 +504,12 @@ def main():
     model.set_compute_dtype(args.dtype)
     # UNETDC_DP_FORCE=1: a one-rank process group whose collectives are really issued (RCCL rehearsal on a one-GPU box)
     force_dp = os.environ.get("UNETDC_DP_FORCE") == "1"
-    wrapper = dpmod.DataParallel(model, single_rank_collectives=force_dp) if (world > 1 or force_dp) else None
+    # UNETDC_DP_BUCKET_MB / UNETDC_DP_MAX_BUCKET_MB: bucket policy of the gradient exchange (experiments; default 16 / 32 MiB)
+    bkt = {}
+    if os.environ.get("UNETDC_DP_BUCKET_MB"):
+        bkt["bucket_bytes"] = int(float(os.environ["UNETDC_DP_BUCKET_MB"]) * (1 << 20))
+        bkt["max_bucket_bytes"] = int(float(os.environ.get("UNETDC_DP_MAX_BUCKET_MB", 2 * float(os.environ["UNETDC_DP_BUCKET_MB"]))) * (1 << 20))
+    wrapper = dpmod.DataParallel(model, single_rank_collectives=force_dp, **bkt) if (world > 1 or force_dp) else None
     # train_DC_focal.py:224 (Adam, lr 1e-3): the same update rule in ONE HIP kernel that also rewrites the packed weight
     # images (unet_dc_segmentation_amd/optim.py); --adam fused / foreach select torch.optim.Adam for comparison
     if args.adam == "hip":
