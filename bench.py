@@ -66,7 +66,7 @@ def igemm_flops(name, a, es=2):
     """(nominal dense FLOPs incl. padded taps, algorithmic bytes = input + weights + output read/written
     once) of one implicit-GEMM launch, from its C-ABI arguments."""
     if name in ("unetdc_conv3x3_fwd", "unetdc_conv3x3_fwd_bnin"):      # (bnin: input = the raw output of the stage in front)
-        n, h, w, cin, cout = a[9:14]
+        n, h, w, cin, cout = a[10:15]
         return 2.0 * n * h * w * cout * cin * 9, (n * h * w * (cin + cout) + 9 * cin * cout) * es
     if name == "unetdc_conv3x3_dgrad":
         n, h, w, cin, cout = a[5:10]
@@ -223,8 +223,8 @@ def executed_fraction(a, name, blocks16=False):
     d % 16 == 0): exactly the in-bounds tap-pixel pairs, 4 of 9 there.  1.0 for transposed convs and the halo-patch kernel."""
     if "convT" in name:
         return 1.0
-    if name == "unetdc_conv3x3_fwd":
-        n, h, w, d = a[9], a[10], a[11], a[14]
+    if name in ("unetdc_conv3x3_fwd", "unetdc_conv3x3_fwd_bnin"):
+        n, h, w, d = a[10], a[11], a[12], a[15]
     elif name == "unetdc_conv3x3_dgrad":
         n, h, w, d = a[5], a[6], a[7], a[10]
     elif name == "unetdc_conv3x3_dgrad_bnstats":
@@ -447,6 +447,219 @@ def self_launch(args, argv):
     return 0
 
 
+IGEMM_CALLS = ["unetdc_conv3x3_fwd", "unetdc_conv3x3_fwd_bnin", "unetdc_conv3x3_dgrad", "unetdc_convT2x2_fwd", "unetdc_convT2x2_dgrad",
+               "unetdc_conv3x3_dgrad_bnstats", "unetdc_convT2x2_dgrad_bnstats", "unetdc_conv3x3_dgrad_colsum"]
+
+
+def _pct(sorted_vals, q):
+    return sorted_vals[min(len(sorted_vals) - 1, max(0, int(round(q * (len(sorted_vals) - 1)))))]
+
+
+def timed_region(step, steps, make_event=None, sync=None, barrier=None, alloc_stats=None):
+    """The timed region and NOTHING else: `steps` calls of step() between barrier + device sync on both sides.
+
+    No per-call instrumentation runs in here (the per-kernel roofline legs are separate passes AFTER it); what is recorded costs
+    one pre-created event record and one perf_counter() per step:
+      * device time per step  -- events at the step boundaries on the launch stream,
+      * host time per step    -- perf_counter() stamps when the host has finished ENQUEUEING each step,
+      * garbage collections   -- gc.callbacks (generation, duration); the cyclic collector is disabled for the region after a
+                                 full collection + gc.freeze() (a generation-2 pass over torch's heap costs 40-60 ms of host time),
+      * allocator activity    -- deltas of the caching allocator's device-malloc / retry counters.
+    make_event / sync / barrier / alloc_stats are injectable so that the CPU suite can run this very function."""
+    import gc
+    make_event = make_event or (lambda: torch.cuda.Event(enable_timing=True))
+    sync = sync or torch.cuda.synchronize
+    alloc_stats = alloc_stats or (lambda: {k: torch.cuda.memory_stats().get(k, 0) for k in ("num_device_alloc", "num_alloc_retries", "num_ooms")})
+    marks = [make_event() for _ in range(steps + 1)]            # created BEFORE the region
+    host = [0.0] * (steps + 1)
+    gc_events, gc_t0 = [], [0.0]
+
+    def on_gc(phase, info):
+        if phase == "start":
+            gc_t0[0] = time.perf_counter()
+        else:
+            gc_events.append({"generation": info.get("generation"), "ms": (time.perf_counter() - gc_t0[0]) * 1e3,
+                              "at_ms": (gc_t0[0] - host[0]) * 1e3, "collected": info.get("collected")})
+
+    gc.collect()
+    gc.freeze()                 # everything alive now (torch, the model, the engine) leaves the collector's generations
+    was_enabled = gc.isenabled()
+    gc.disable()
+    gc.callbacks.append(on_gc)
+    a0 = alloc_stats()
+    loss = None
+    try:
+        if barrier:
+            barrier()
+        sync()
+        t0 = time.perf_counter()
+        host[0] = t0
+        marks[0].record()
+        for i in range(steps):
+            loss = step()
+            marks[i + 1].record()
+            host[i + 1] = time.perf_counter()
+        sync()
+        if barrier:
+            barrier()
+        elapsed = time.perf_counter() - t0
+    finally:
+        gc.callbacks.remove(on_gc)
+        if was_enabled:
+            gc.enable()
+        gc.unfreeze()
+    a1 = alloc_stats()
+    dev_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+    host_ms = [(host[i + 1] - host[i]) * 1e3 for i in range(steps)]
+    srt = sorted(dev_ms)
+    imax = dev_ms.index(srt[-1])
+    stats = {"median": _pct(srt, 0.5), "p10": _pct(srt, 0.1), "p90": _pct(srt, 0.9), "min": srt[0], "max": srt[-1],
+             "max_at_step": imax, "n": steps,
+             "host_ms_at_max": host_ms[imax], "host_ms_median": _pct(sorted(host_ms), 0.5), "host_ms_max": max(host_ms),
+             "host_max_at_step": host_ms.index(max(host_ms)),
+             # how far the host ran ahead of the device when the slowest step was enqueued (ms of queued work): > 0 means a
+             # host pause of that size would have been hidden
+             "host_lead_ms_at_max": sum(dev_ms[:imax + 1]) - (host[imax + 1] - host[0]) * 1e3,
+             "gc_events": gc_events, "gc": "collect + freeze + disable around the timed region",
+             "device_allocs_in_timed_region": a1.get("num_device_alloc", 0) - a0.get("num_device_alloc", 0),
+             "alloc_retries_in_timed_region": a1.get("num_alloc_retries", 0) - a0.get("num_alloc_retries", 0),
+             "measured": "HIP events on the launch stream at the step boundaries + host perf_counter stamps after each "
+                         "step's enqueue (rank 0); no per-call events inside the region"}
+    return elapsed, stats, loss
+
+
+def igemm_leg(step, dtype, mode, nsteps=3, headline=False):
+    """Instrumented pass AFTER the timed region: HIP events around every implicit-GEMM C-ABI call of `nsteps` steps (on the
+    stream the kernels are launched on), grouped per dispatched kernel; the dominant one (most time per step) gives `roofline`.
+    Per-kernel time = MEDIAN over its launches of the same shape group (one outlier launch does not move it)."""
+    from unet_dc_segmentation_amd import _lib
+    es = 2 if dtype == "bf16" else 4
+    _lib.start_timing(IGEMM_CALLS)
+    for _ in range(nsteps):
+        step()
+    records = _lib.stop_timing()
+    groups = {}
+    for tagged, a, ms in records:
+        name, key = tagged.split("|")              # C-ABI entry point | dispatched kernel symbol
+        fl, nbytes = igemm_flops(name, a, es)
+        gsum = groups.setdefault(key, [0.0, [], 0, 0.0, 0.0])
+        gsum[0] += fl
+        gsum[1].append(ms)
+        gsum[2] += 1
+        gsum[3] += nbytes
+        gsum[4] += fl * (executed_fraction(a, name, "blocks16x16" in key) if "dma" in key else 1.0)
+    peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
+    kernels = []
+    for key, (fl, mss, cnt, nbytes, flx) in groups.items():
+        ms = sum(mss)
+        kernels.append({"kernel": key, "launches_per_step": cnt / nsteps, "avg_launch_ms": ms / cnt,
+                        "median_launch_ms": sorted(mss)[len(mss) // 2],
+                        "gflop_per_launch": fl / cnt / 1e9, "tflops": fl / (ms * 1e-3) / 1e12,
+                        "executed_gflop_per_launch": flx / cnt / 1e9, "tflops_executed": flx / (ms * 1e-3) / 1e12,
+                        "ms_per_step": ms / nsteps, "algorithmic_bytes_per_launch": nbytes / cnt})
+    kernels.sort(key=lambda k: -k["ms_per_step"])
+    dom = kernels[0]
+    roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak,
+                "unit": "TFLOP/s", "frac": dom["tflops"] / peak,
+                "empirical_peak": EMPIRICAL_BF16_TFLOPS if dtype == "bf16" else None,
+                "frac_of_empirical": dom["tflops"] / EMPIRICAL_BF16_TFLOPS if dtype == "bf16" else None,
+                "traffic": pmc_traffic(dom["kernel"]) if headline else None,
+                "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
+                "flop_per_launch": dom["gflop_per_launch"] * 1e9,
+                "executed_flop_per_launch": dom["executed_gflop_per_launch"] * 1e9,
+                "flop_note": "nominal dense FLOPs, padded taps included (SURVEY 8d); executed = after block-level "
+                             "skipping of taps that cannot reach the image",
+                "avg_launch_ms": dom["avg_launch_ms"], "launches_per_step": dom["launches_per_step"],
+                "measured": f"HIP events around each call on the launch stream, {nsteps} instrumented steps AFTER the timed region",
+                "igemm_ms_per_step": sum(k["ms_per_step"] for k in kernels)}
+    if headline:
+        roofline["all_igemm_kernels"] = kernels
+    else:
+        roofline["top_kernels"] = [{k: v for k, v in kk.items() if k in ("kernel", "launches_per_step", "tflops", "ms_per_step")}
+                                   for kk in kernels[:3]]
+    return roofline
+
+
+NOMINAL_GFLOP_IMG = {("train", 512): 1153.9, ("infer", 512): 384.74, ("train", 1024): 4615.6, ("infer", 1024): 1538.94}   # SURVEY 8d, C_in = 1
+
+
+class Job:
+    """One workload of this rank: module, optimizer, resident synthetic batch, step()."""
+
+    def __init__(self, mode, dtype, batch, size, cin, arch, adam, dev, rank=0):
+        from utils.metrics_DC import focal_dice_loss
+        if arch == "unetdc":
+            from models.model_2 import UNetDC as Net
+        else:
+            from models.model import UNet as Net
+        self.mode, self.dtype, self.batch, self.size, self.cin, self.arch, self.adam = mode, dtype, batch, size, cin, arch, adam
+        torch.manual_seed(0)                                   # identical replicas
+        self.model = Net(in_channels=cin, out_channels=1).to(dev)
+        self.model.train() if mode == "train" else self.model.eval()
+        self.model.set_compute_dtype(dtype)
+        self.opt = None
+        x, t = synthetic_batch(1000 + rank, batch, size, size, cin)
+        self.x, self.t = x.to(dev), t.to(dev)
+        self._loss = focal_dice_loss
+
+    def make_optimizer(self):
+        # train_DC_focal.py:224 (Adam, lr 1e-3): the same update rule in ONE HIP kernel that also rewrites the packed weight
+        # images (unet_dc_segmentation_amd/optim.py); --adam fused / foreach select torch.optim.Adam for comparison
+        if self.mode != "train":
+            return
+        if self.adam == "hip":
+            from unet_dc_segmentation_amd.optim import FusedAdam
+            self.opt = FusedAdam(self.model, lr=1e-3)
+        else:
+            self.opt = torch.optim.Adam(self.model.parameters(), lr=1e-3, fused=(self.adam == "fused"))
+
+    def step(self):
+        if self.mode == "train":
+            self.opt.zero_grad(set_to_none=True)
+            p = self.model(self.x)
+            loss = self._loss(p, self.t, alpha=1.0, gamma=2.0, ratio=0.3)      # train_DC_focal.py:222
+            loss.backward()
+            self.opt.step()
+            return loss
+        with torch.no_grad():                                   # quantify_droplets_batch.py:51-56 on device
+            p = self.model(self.x)
+            return (p > 0.3).sum()
+
+    def workload(self, world=1):
+        if self.mode == "train":
+            return (f"train step (fwd + Focal/Dice loss + bwd + Adam{' + RCCL grad all-reduce' if world > 1 else ''}) "
+                    f"{self.arch} bs={self.batch}/GPU {self.size}x{self.size}x{self.cin} {self.dtype}")
+        return f"eval forward + 0.3 threshold, {self.arch} bs={self.batch}/GPU {self.size}x{self.size}x{self.cin} {self.dtype}"
+
+
+def secondary_entry(dev, label, mode, dtype, batch, size, steps, warmup=2):
+    """One more single-GPU BASELINE configuration, measured like the headline (own timed region, own instrumented pass)."""
+    job = Job(mode, dtype, batch, size, 1, "unetdc", "hip", dev)
+    job.make_optimizer()
+    job.step()                                             # initialisation (buffers, descriptor tables)
+    torch.cuda.synchronize()
+    for _ in range(warmup):
+        job.step()
+    elapsed, stats, _ = timed_region(job.step, steps)
+    roof = igemm_leg(job.step, dtype, mode, nsteps=2)
+    imgs = batch * steps
+    gf = NOMINAL_GFLOP_IMG.get((mode, size))
+    ent = {"config": {"workload": job.workload() + f" ({label})", "global_batch": batch, "parallelism": "dp1"},
+           "metric": "images/sec " + ("fwd+bwd" if mode == "train" else "forward-only inference"),
+           "value": imgs / elapsed, "unit": "images/s", "dtype": dtype, "steps": steps, "warmup": warmup,
+           "ms_per_step": elapsed / steps * 1e3,
+           "step_ms": {k: stats[k] for k in ("median", "min", "max", "p90", "n", "host_ms_median")},
+           "roofline": roof}
+    if gf:
+        tf = gf * 1e9 * imgs / elapsed / 1e12
+        peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
+        ent["whole_step_tflops_nominal"] = tf
+        ent["whole_step_frac_of_mfma_peak"] = tf / peak
+    del job
+    torch.cuda.empty_cache()
+    return ent
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -458,6 +671,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--arch", default="unetdc", choices=["unetdc", "unet"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the other single-GPU BASELINE configurations (fp32 inference, 1024x1024 bs 4, fp32 training) "
+                         "that the default N = 1 training run measures after the headline")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--adam", choices=["hip", "fused", "foreach"], default="hip",
                     help="hip = this repo's one-kernel Adam + weight re-pack (default); fused / foreach = torch.optim.Adam")
@@ -480,8 +696,7 @@ def main():
         assert torch.cuda.is_available(), "bench.py needs a HIP device"
         quantify_bench(args, real_stdout)
         return
-    from unet_dc_segmentation_amd import _lib, dp as dpmod
-    from utils.metrics_DC import focal_dice_loss
+    from unet_dc_segmentation_amd import dp as dpmod
     # RCCL ("nccl") is the production backend; UNETDC_DIST_BACKEND=gloo + UNETDC_BENCH_DEVICE=0 lets several
     # ranks rehearse the multi-rank code path on ONE card (RCCL refuses two ranks per device).
     backend = os.environ.get("UNETDC_DIST_BACKEND", "nccl")
@@ -495,13 +710,8 @@ def main():
     dev = torch.device("cuda", local)
     import torch.distributed as dist
 
-    if args.arch == "unetdc":
-        from models.model_2 import UNetDC as Net
-    else:
-        from models.model import UNet as Net
-    torch.manual_seed(0)                                   # identical replicas
-    model = Net(in_channels=args.in_channels, out_channels=1).to(dev).train()
-    model.set_compute_dtype(args.dtype)
+    job = Job(args.mode, args.dtype, args.batch, args.size, args.in_channels, args.arch, args.adam, dev, rank)
+    model = job.model
     # UNETDC_DP_FORCE=1: a one-rank process group whose collectives are really issued (RCCL rehearsal on a one-GPU box)
     force_dp = os.environ.get("UNETDC_DP_FORCE") == "1"
     # UNETDC_DP_BUCKET_MB / UNETDC_DP_MAX_BUCKET_MB: bucket policy of the gradient exchange (experiments; default 16 / 32 MiB)
@@ -510,32 +720,8 @@ def main():
         bkt["bucket_bytes"] = int(float(os.environ["UNETDC_DP_BUCKET_MB"]) * (1 << 20))
         bkt["max_bucket_bytes"] = int(float(os.environ.get("UNETDC_DP_MAX_BUCKET_MB", 2 * float(os.environ["UNETDC_DP_BUCKET_MB"]))) * (1 << 20))
     wrapper = dpmod.DataParallel(model, single_rank_collectives=force_dp, **bkt) if (world > 1 or force_dp) else None
-    # train_DC_focal.py:224 (Adam, lr 1e-3): the same update rule in ONE HIP kernel that also rewrites the packed weight
-    # images (unet_dc_segmentation_amd/optim.py); --adam fused / foreach select torch.optim.Adam for comparison
-    if args.adam == "hip":
-        from unet_dc_segmentation_amd.optim import FusedAdam
-        opt = FusedAdam(model, lr=1e-3)
-    else:
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=(args.adam == "fused"))
-    x, t = synthetic_batch(1000 + rank, args.batch, args.size, args.size, args.in_channels)
-    x, t = x.to(dev), t.to(dev)
-
-    def train_step():
-        opt.zero_grad(set_to_none=True)
-        p = model(x)
-        loss = focal_dice_loss(p, t, alpha=1.0, gamma=2.0, ratio=0.3)      # train_DC_focal.py:222
-        loss.backward()
-        opt.step()
-        return loss
-
-    def infer_step():                                      # quantify_droplets_batch.py:51-56 on device
-        with torch.no_grad():
-            p = model(x)
-            return (p > 0.3).sum()
-
-    if args.mode == "infer":
-        model.eval()
-    step = train_step if args.mode == "train" else infer_step
+    job.make_optimizer()
+    step = job.step
 
     # initialisation, not warm-up: the engine behind the module allocates its activation / gradient buffers and builds its
     # descriptor tables on the first forward / backward / optimizer step (like cudnn.benchmark or lazy module init would);
@@ -544,74 +730,36 @@ def main():
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
-    igemm_calls = ["unetdc_conv3x3_fwd", "unetdc_conv3x3_fwd_bnin", "unetdc_conv3x3_dgrad", "unetdc_convT2x2_fwd", "unetdc_convT2x2_dgrad",
-                   "unetdc_conv3x3_dgrad_bnstats", "unetdc_convT2x2_dgrad_bnstats", "unetdc_conv3x3_dgrad_colsum"]
     if args.per_layer:
         per_layer_table(step, args)
+    elapsed, step_stats, loss = timed_region(step, args.steps, barrier=dist.barrier if world > 1 else None)
+    local_elapsed = elapsed
+    ranks = None
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    _lib.start_timing(igemm_calls)
-    # per-step device time: one HIP event per step boundary on the launch stream (recording does not synchronise)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(args.steps):
-        loss = step()
-        marks[i + 1].record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    records = _lib.stop_timing()
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        # MAX over ranks is the job's time; every rank's own time and median step go into the line as well
+        mine = torch.tensor([elapsed, step_stats["median"], step_stats["max"]], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per = torch.stack(allr).cpu()
+        elapsed = float(per[:, 0].max())
+        med = sorted(float(v) for v in per[:, 1])
+        ranks = {"ranks_seen": dist.get_world_size(), "elapsed_s_per_rank": [float(v) for v in per[:, 0]],
+                 "step_ms_median_across_ranks": {"min": med[0], "median": med[len(med) // 2], "max": med[-1]},
+                 "step_ms_max_across_ranks": float(per[:, 2].max())}
     final_loss = float(loss.item())
-    raw_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
-    step_ms = sorted(raw_ms)
-    pct = lambda q: step_ms[min(len(step_ms) - 1, max(0, int(round(q * (len(step_ms) - 1)))))]   # noqa: E731
-    step_stats = {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "min": step_ms[0], "max": step_ms[-1], "max_at_step": raw_ms.index(step_ms[-1]),
-                  "n": len(step_ms),
-                  "measured": "HIP events on the launch stream at the step boundaries of the timed region (rank 0)"}
+    # ---- instrumented passes, all AFTER the timed region (every rank runs them: the collectives need all ranks) ----
+    roofline = igemm_leg(step, args.dtype, args.mode, nsteps=3, headline=(args.mode == "train" and args.dtype == "bf16"))
     hbm = hbm_leg(step, 2 if args.dtype == "bf16" else 4) if args.mode == "train" else None
+    coll = None
+    if wrapper is not None and args.mode == "train":
+        wrapper.start_trace()
+        for _ in range(3):
+            wrapper.mark_step_start()
+            step()
+        coll = wrapper.stop_trace()
 
     if rank == 0:
-        # ---- roofline of the dominant kernel -------------------------------------------------
-        groups = {}
-        for tagged, a, ms in records:
-            name, key = tagged.split("|")              # C-ABI entry point | dispatched kernel symbol
-            fl, nbytes = igemm_flops(name, a, 2 if args.dtype == "bf16" else 4)
-            gsum = groups.setdefault(key, [0.0, 0.0, 0, 0.0, 0.0])
-            gsum[0] += fl
-            gsum[1] += ms
-            gsum[2] += 1
-            gsum[3] += nbytes
-            gsum[4] += fl * (executed_fraction(a, name, "blocks16x16" in key) if "dma" in key else 1.0)
-        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-        kernels = []
-        for key, (fl, ms, cnt, nbytes, flx) in groups.items():
-            kernels.append({"kernel": key, "launches_per_step": cnt / args.steps, "avg_launch_ms": ms / cnt,
-                            "gflop_per_launch": fl / cnt / 1e9, "tflops": fl / (ms * 1e-3) / 1e12,
-                            "executed_gflop_per_launch": flx / cnt / 1e9, "tflops_executed": flx / (ms * 1e-3) / 1e12,
-                            "ms_per_step": ms / args.steps, "algorithmic_bytes_per_launch": nbytes / cnt})
-        kernels.sort(key=lambda k: -k["ms_per_step"])
-        dom = kernels[0]
-        roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": peak,
-                    "unit": "TFLOP/s", "frac": dom["tflops"] / peak,
-                    "empirical_peak": EMPIRICAL_BF16_TFLOPS if args.dtype == "bf16" else None,
-                    "frac_of_empirical": dom["tflops"] / EMPIRICAL_BF16_TFLOPS if args.dtype == "bf16" else None,
-                    "traffic": pmc_traffic(dom["kernel"]) if args.mode == "train" and args.dtype == "bf16" else None,
-                    "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
-                    "flop_per_launch": dom["gflop_per_launch"] * 1e9,
-                    "executed_flop_per_launch": dom["executed_gflop_per_launch"] * 1e9,
-                    "flop_note": "nominal dense FLOPs, padded taps included (SURVEY 8d); executed = after block-level "
-                                 "skipping of taps that cannot reach the image",
-                    "avg_launch_ms": dom["avg_launch_ms"],
-                    "launches_per_step": dom["launches_per_step"], "all_igemm_kernels": kernels}
-        nominal_gflop_img = ((1153.9 if args.mode == "train" else 384.74)
-                             if (args.size == 512 and args.in_channels == 1) else None)
+        nominal_gflop_img = NOMINAL_GFLOP_IMG.get((args.mode, args.size)) if args.in_channels == 1 else None
         imgs = args.batch * world * args.steps
         out = {
             "metric": (f"images/sec fwd+bwd, {args.size}x{args.size}x{args.in_channels} "
@@ -621,11 +769,7 @@ def main():
             "value": imgs / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": (f"train step (fwd + Focal/Dice loss + bwd + Adam{' + RCCL grad all-reduce' if world > 1 else ''}) "
-                                    f"{args.arch} bs={args.batch}/GPU {args.size}x{args.size}x{args.in_channels} "
-                                    "(BASELINE configs[2]/[3])") if args.mode == "train" else
-                                   (f"eval forward + 0.3 threshold, {args.arch} bs={args.batch}/GPU "
-                                    f"{args.size}x{args.size}x{args.in_channels} (BASELINE configs[1])"),
+            "config": {"workload": job.workload(world) + (" (BASELINE configs[2]/[3])" if args.mode == "train" else " (BASELINE configs[1])"),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "init_steps_before_warmup": 1,
                        "timed_region": "zero_grad, model(x), focal_dice_loss, backward, all-reduce, Adam step (" + args.adam + "), weight re-pack"
                                        if args.mode == "train" else "model(x) under no_grad + threshold, input resident in HBM"},
@@ -636,10 +780,24 @@ def main():
         }
         if nominal_gflop_img:
             out["whole_step_tflops_nominal"] = nominal_gflop_img * 1e9 * imgs / elapsed / 1e12
+            out["whole_step_frac_of_mfma_peak"] = out["whole_step_tflops_nominal"] / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS)
         if wrapper is not None:
             out["allreduce_buckets_per_step"] = wrapper.stats["buckets"] / max(wrapper.stats["steps"], 1)
             out["collective"] = {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "ranks": world,
                                  "payload_MB_per_step": wrapper.stats["elems"] * 4 / max(wrapper.stats["steps"], 1) / 1e6}
+            if coll:
+                out["collective"].update(coll)
+        if ranks:
+            out["ranks"] = ranks
+        if world == 1 and wrapper is None and args.mode == "train" and not args.no_secondary:
+            # the other single-GPU BASELINE configurations, each with its own timed region (<= 10 s together)
+            del job, model, step
+            torch.cuda.empty_cache()
+            out["secondary"] = [
+                secondary_entry(dev, "BASELINE configs[1]: forward-only inference, parity dtype", "infer", "f32", 8, 512, steps=15),
+                secondary_entry(dev, "BASELINE configs[4] per GPU: 1024x1024 tiles bs 4", "train", "bf16", 4, 1024, steps=15),
+                secondary_entry(dev, "configs[2] in the parity dtype: fp32 training step", "train", "f32", 8, 512, steps=8),
+            ]
         if world == 1 and not args.no_cpu_baseline and args.mode == "train":
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.size, args.size, args.in_channels)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define UNETDC_ABI_VERSION 1
+#define UNETDC_ABI_VERSION 2
 
 #define UNETDC_F32 0
 #define UNETDC_BF16 1
@@ -97,13 +97,12 @@ int unetdc_adam_step(const unetdc_adam_desc* table_dev, int n, int64_t total_blo
  * as stored, rows = unetdc_conv3x3_stats_rows(); the buffer must hold rows+64 rows.
  * Cin must be a multiple of 64 (bf16) / 32 (fp32) and Cout of 64: every layer but enc1.0. */
 int unetdc_conv3x3_stats_rows(int64_t npixels, int cout);
-/* Rows of the statistics buffer that carry data after the last unetdc_conv3x3_fwd call of this thread that was asked for
- * statistics (<= unetdc_conv3x3_stats_rows(): the persistent kernels write one row per workgroup and zeros into the
- * rest, so summing all rows stays valid; passing this count to unetdc_bn_finalize saves it reading the zero rows). */
-int unetdc_last_stats_rows(void);
+/* stats_rows (out, nullable; written when stats_part is given): rows of the statistics buffer that carry data
+ * (<= unetdc_conv3x3_stats_rows(): the persistent kernels write one row per workgroup and zeros into the rest, so
+ * summing all rows stays valid; passing this count to unetdc_bn_finalize saves it reading the zero rows). */
 int unetdc_conv3x3_fwd(const void* x, int ldx, const void* w_fwd, const float* bias, const float* scale,
-                       const float* shift, void* y, int ldy, float* stats_part, int n, int h, int w, int cin,
-                       int cout, int dilation, int dtype, unetdc_stream_t s);
+                       const float* shift, void* y, int ldy, float* stats_part, int* stats_rows, int n, int h, int w,
+                       int cin, int cout, int dilation, int dtype, unetdc_stream_t s);
 /* "bnin" forms (round 3): the convolution / weight gradient are fed from the RAW conv output of the stage in front of them and
  * apply that stage's BatchNorm + ReLU -- relu(in_scale * x + in_shift), models/model_2.py:45-46, rounded through the storage
  * type like a stored activation -- once per staged tile in LDS: the stand-alone unetdc_bn_relu_apply pass of that stage and
@@ -112,8 +111,8 @@ int unetdc_conv3x3_fwd(const void* x, int ldx, const void* w_fwd, const float* b
  * fwd: statistics mode only (training); in_scale / in_shift [cin] are the producing stage's batch scale / shift. */
 int unetdc_conv3x3_bnin_supported(int n, int h, int w, int cin, int cout, int dilation, int dtype);
 int unetdc_conv3x3_fwd_bnin(const void* x_raw, int ldx, const float* in_scale, const float* in_shift, const void* w_fwd,
-                            const float* bias, void* y, int ldy, float* stats_part, int n, int h, int w, int cin, int cout,
-                            int dilation, int dtype, unetdc_stream_t s);
+                            const float* bias, void* y, int ldy, float* stats_part, int* stats_rows, int n, int h, int w,
+                            int cin, int cout, int dilation, int dtype, unetdc_stream_t s);
 int unetdc_conv3x3_wgrad_bnin(const void* x_raw, int ldx, const float* in_scale, const float* in_shift, const void* dy,
                               int lddy, float* dw, void* workspace, int64_t workspace_bytes, int n, int h, int w, int cin,
                               int cout, int dilation, int dtype, unetdc_stream_t s);

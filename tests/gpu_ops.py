@@ -1,4 +1,6 @@
 """Thin test-side wrappers over the C ABI (raw pointers through ctypes) + layout helpers."""
+import ctypes
+
 import torch
 
 from unet_dc_segmentation_amd import _lib
@@ -6,6 +8,9 @@ from unet_dc_segmentation_amd._lib import call
 
 TD = {"f32": torch.float32, "bf16": torch.bfloat16}
 DT = {"f32": _lib.F32, "bf16": _lib.BF16}
+
+
+LIVE_ROWS = ctypes.c_int(-1)      # stats_rows out-parameter of the last conv3x3_fwd() below (rows that carry data)
 
 
 def stream():
@@ -57,9 +62,11 @@ def pack_convT(w, dtype):
 def conv3x3_fwd(xv, wf, bias, n, h, w, cin, cout, d, dtype, yv, stats=False, scale=None, shift=None):
     rows = _lib.load().unetdc_conv3x3_stats_rows(n * h * w, cout)
     st = torch.full(((rows + 64) * 2 * cout,), float("nan"), device="cuda") if stats else None
+    LIVE_ROWS.value = -1
     call("unetdc_conv3x3_fwd", xv.data_ptr(), xv.stride(0), wf.data_ptr(), None if bias is None else bias.data_ptr(),
          None if scale is None else scale.data_ptr(), None if shift is None else shift.data_ptr(), yv.data_ptr(),
-         yv.stride(0), None if st is None else st.data_ptr(), n, h, w, cin, cout, d, DT[dtype], stream())
+         yv.stride(0), None if st is None else st.data_ptr(), ctypes.byref(LIVE_ROWS), n, h, w, cin, cout, d, DT[dtype],
+         stream())
     return st, rows
 
 

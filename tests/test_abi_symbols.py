@@ -48,16 +48,16 @@ def test_ctypes_table_matches_header(lib):
 
 
 def test_host_only_queries_and_error_reporting(lib):
-    assert lib.unetdc_version() == 1
+    assert lib.unetdc_version() == 2
     # pure host-side planning queries (no device needed)
     assert lib.unetdc_conv3x3_stats_rows(8 * 512 * 512, 64) == 8192
     assert lib.unetdc_conv3x3_stats_rows(8 * 32 * 32, 1024) == 32
     assert lib.unetdc_conv3x3_wgrad_workspace(8, 512, 512, 64, 64, 1) > 0
     assert lib.unetdc_bn_relu_bwd_workspace(8, 512, 512, 64, 1, 1) > 0
     # argument validation happens before any HIP call: bad shapes give a negative code + message
-    rc = lib.unetdc_conv3x3_fwd(None, 64, None, None, None, None, None, 64, None, 1, 8, 8, 64, 64, 1, 0, None)
+    rc = lib.unetdc_conv3x3_fwd(None, 64, None, None, None, None, None, 64, None, None, 1, 8, 8, 64, 64, 1, 0, None)
     assert rc == -1 and b"null" in lib.unetdc_last_error()
-    rc = lib.unetdc_conv3x3_fwd(None, 64, None, None, None, None, None, 64, None, 0, 8, 8, 64, 64, 1, 0, None)
+    rc = lib.unetdc_conv3x3_fwd(None, 64, None, None, None, None, None, 64, None, None, 0, 8, 8, 64, 64, 1, 0, None)
     assert rc == -1 and b"geometry" in lib.unetdc_last_error()
 
 

@@ -58,10 +58,19 @@ def _worker(rank, world, port, q, full=True):
             o += p.numel()
         flat = torch.full((o,), float(rank + 1))
         flat[:1000] += torch.arange(1000.0) * (rank + 1)
+        dp.start_trace()                                    # the timeline bench.py puts into its N > 1 line (collective.*)
+        dp.mark_step_start()
         for mods in _stage_order(model):
             ps = [p for m in mods for p in m.parameters()]
             dp._on_ready(flat, offs[id(ps[0])], offs[id(ps[-1])] + ps[-1].numel())
         dp.finish()
+        coll = dp.stop_trace()
+        assert coll["traced_steps"] == 1 and coll["exposed_ms_per_step"] >= 0.0 and "perf_counter" in coll["clock"]
+        assert [round(b["MB"], 1) for b in coll["buckets"]] == [21.5, 18.9, 23.1, 23.1, 18.9, 17.7, 1.0]
+        assert all(0.0 <= b["ready_at_ms"] <= b["done_at_ms"] for b in coll["buckets"])
+        assert [b["ready_at_ms"] for b in coll["buckets"]] == sorted(b["ready_at_ms"] for b in coll["buckets"])
+        assert round(dp.stats["elems"] * 4 / max(dp.stats["steps"], 1) / 1e6, 1) == 124.2        # bench.py's collective.payload_MB_per_step
+        assert dp._trace is None                            # tracing is off again: the training loop records nothing
         # the bucket schedule DESIGN.md section 5 states (fp32 MB): head...dec4.3 | dec4.0 | upconv4 + bottleneck.3 cut in
         # two | bottleneck.0 | enc4 + enc3 | enc2 + enc1 at finish()
         assert [round(n * 4 / 1e6, 1) for n in dp.schedule] == [21.5, 18.9, 23.1, 23.1, 18.9, 17.7, 1.0], dp.schedule

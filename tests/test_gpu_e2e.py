@@ -289,8 +289,11 @@ def test_full_size_eval_mask_bf16_agreement_with_fp32_reference():
                 f.write(f"vs {k}: equal {v[0] * 100:.4f} % of 2097152 pixels; max|dz| {v[1]:.4e}; mean|dz| {v[2]:.4e}; farthest flipped "
                         f"pixel {v[3]:.4e} from the threshold; worst |dz| among flips {v[4]:.4e}\n")
     assert 0.3 < float((z32 > recipe.LOGIT_THRESH).double().mean()) < 0.7
-    assert a32[0] > 0.97 and aem[0] > 0.97, (a32, aem)
-    assert a32[1] < 0.25, a32                              # logits: bf16 storage, 23 layers deep (the fp32 path: < 1e-3)
+    # bands = a few times what was MEASURED on MI355X (round 4: 99.575 % / 99.469 % of the pixels equal, max |dz| 5.0e-3 /
+    # 6.5e-3, mean |dz| 8.0e-4 / 1.0e-3): a 4x regression of the bf16 path fails here (the fp32 path's bar is 1e-3, above)
+    assert a32[0] > 0.99 and aem[0] > 0.99, (a32, aem)
+    assert a32[1] < 2e-2 and aem[1] < 2e-2, (a32, aem)    # max |dz|: bf16 storage, 23 layers deep
+    assert a32[2] < 3e-3 and aem[2] < 3e-3, (a32, aem)    # mean |dz|
 
 
 def test_full_size_bf16_gradients_vs_bf16_emulating_oracle():
@@ -338,6 +341,47 @@ def test_full_size_bf16_gradients_vs_bf16_emulating_oracle():
     for k, c_he, c_hf, c_ef in rows:
         assert c_hf >= c_ef - 0.03, (k, c_hf, c_ef)
         assert c_he > (0.999 if k.startswith("dec1") else 0.94), (k, c_he)
+
+
+def test_full_size_train_step_fp32_vs_cpu_port():
+    """BASELINE configs[2]'s shape in the PARITY dtype: 8 x 1 x 512 x 512, fp32 forward + Focal/Dice loss + backward on the HIP
+    path vs the CPU port of the reference (oracle/unetdc_torch_cpu.py: the ATen ops the reference calls), same weights, same
+    batch.  Bars: loss within 1e-5 relative, probabilities within 1e-4; every weight gradient's rel-L2 distance from the CPU
+    result <= 4x the CPU path's OWN distance from a rerun on a 1-ulp-perturbed input (the conditioning yardstick of
+    test_train_step_fp32_matches_golden_and_fp64: ReLU / max-pool ties that flip under any fp32 evaluation order), floor 2e-5."""
+    from models.model_2 import UNetDC
+    from utils.metrics_DC import focal_dice_loss
+    torch.manual_seed(31)
+    model = UNetDC(1, 1)
+    dil = dict(model.DILATIONS)
+    x = recipe.seeded_input(32, (8, 1, 512, 512))
+    t = recipe.seeded_target(33, (8, 1, 512, 512), frac=0.1)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    loss_ref, p_ref, g_ref = otc.train_step_grads(x, t, {k: v.clone() for k, v in sd.items()}, dil)
+    torch.manual_seed(0)
+    xs = x * (1 + (torch.rand_like(x) - 0.5) * 2.4e-7)                   # one 1-ulp perturbation of the input
+    _, _, g_pert = otc.train_step_grads(xs, t, {k: v.clone() for k, v in sd.items()}, dil)
+    model = model.cuda().train()                                          # compute dtype "f32" is the module's default
+    p = model(x.cuda())
+    loss = focal_dice_loss(p, t.cuda(), alpha=1.0, gamma=2.0, ratio=0.3)
+    loss.backward()
+    assert abs(loss.item() - float(loss_ref)) <= 1e-5 * abs(float(loss_ref)), (loss.item(), float(loss_ref))
+    assert float((p.detach().cpu() - p_ref).abs().max()) < 1e-4
+    worst, rows = 0.0, []
+    for k, prm in model.named_parameters():
+        ref = g_ref[k].double()
+        n = float(ref.norm())
+        if k.endswith(".0.bias") or k.endswith(".3.bias"):
+            assert float(prm.grad.abs().max()) < 1e-4, k                  # structural zero in front of train-mode BatchNorm
+            continue
+        e_hip = float((prm.grad.cpu().double() - ref).norm()) / max(n, 1e-30)
+        e_self = float((g_pert[k].double() - ref).norm()) / max(n, 1e-30)
+        rows.append((k, e_hip, e_self))
+        worst = max(worst, e_hip / max(e_self, 5e-6))
+        assert e_hip <= max(4.0 * e_self, 2e-5), (k, e_hip, e_self)
+    top = sorted(rows, key=lambda r: -r[1])[:4]
+    print(f"[full-size fp32 train step] loss {loss.item():.7f} vs CPU {float(loss_ref):.7f}; worst gradient error ratio "
+          f"HIP / CPU-self-noise = {worst:.2f}; largest rel-L2: " + ", ".join(f"{k}={a:.2e} (cpu noise {b:.2e})" for k, a, b in top))
 
 
 def test_full_size_train_step_bf16_properties():
@@ -494,6 +538,16 @@ def test_two_live_forwards_and_a_validation_forward_before_the_backwards():
             model(x)
     with pytest.raises(UnetdcError, match="overwritten by a later forward"):
         loss.backward()
+    # an in-place edit of the returned probabilities (read by the head backward) between forward and backward is caught by
+    # autograd's saved-tensor version check, as for any ATen module
+    model.zero_grad(set_to_none=True)
+    p5 = model(x)
+    loss5 = loss_of(p5)
+    with torch.no_grad():
+        p5.mul_(0.5)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        loss5.backward()
+
 
 def test_1024_tiles_bf16_train_step():
     """BASELINE configs[4] per GPU: 4 x 1 x 1024 x 1024, bf16 storage / fp32 accumulate.  Bitwise run-to-run
@@ -520,6 +574,16 @@ def test_1024_tiles_bf16_train_step():
     assert snaps[0][0] == snaps[1][0]
     for a, b in zip(*[s[1] for s in snaps]):
         assert torch.equal(a, b) and torch.isfinite(a).all()
+    # VALUES of the bs-4 step (the CPU evaluation below covers a bs-2 sub-batch only): against the fp32 HIP path on the same
+    # batch and weights -- the parity-pinned dtype (test_1024_tile_eval_mask_fp32, test_full_size_train_step_fp32_vs_cpu_port)
+    m32 = UNetDC(1, 1)
+    m32.load_state_dict(sd)
+    m32 = m32.cuda().train()
+    p32 = m32(xc)
+    loss32 = focal_dice_loss(p32, tc, alpha=1.0, gamma=2.0, ratio=0.3)
+    assert abs(snaps[0][0] - loss32.item()) < 1e-2 * loss32.item(), (snaps[0][0], loss32.item())
+    assert float((p.detach() - p32.detach()).abs().max()) < 3e-2
+    del m32, p32, loss32
     model.zero_grad(set_to_none=True)
     p = model(xc[:2])
     loss = focal_dice_loss(p, tc[:2], alpha=1.0, gamma=2.0, ratio=0.3)

@@ -164,14 +164,27 @@ def op_fixtures(met):
     print("[ops] known-answer focal_dice_loss(p=0.5,t=0) =", out["loss_known"])
 
 
+def droplet_table_fixture():
+    """The reference's own sample OUTPUT (outputs/all_droplets.csv: 303 droplets of its run on its sample images, pixel size
+    3.45 px/um) as a data fixture: area -> equivalent_diameter / area_sqmicron / eq_diam_micron known answers for
+    quantify_droplets_batch._droplet_table (tests/test_entry_points_cpu.py).  The inputs of that run (images, checkpoint) are
+    not in the reference, so the rows pin the column FORMULAS, nothing else (SURVEY section 2 #14)."""
+    import shutil
+    shutil.copyfile(f"{REF}/outputs/all_droplets.csv", os.path.join(OUT, "ref_all_droplets.csv"))
+    print("[droplets] copied the reference's sample output table:", sum(1 for _ in open(os.path.join(OUT, "ref_all_droplets.csv"))) - 1, "rows")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--droplets-only" in sys.argv:
+        return droplet_table_fixture()
     torch.set_num_threads(8)
     m2, m1, met = ref_modules()
     op_fixtures(met)
     e2e_fixture(m2.UNetDC, 1, 1234, "dc_c1", met)
     e2e_fixture(m2.UNetDC, 3, 4321, "dc_c3", met)
     e2e_fixture(m1.UNet, 3, 2468, "plain_c3", met)
+    droplet_table_fixture()
 
 
 if __name__ == "__main__":

@@ -49,7 +49,7 @@ app_bytes = 2.0 * ya.numel() * 2
 
 def conv(s):
     _lib.call("unetdc_conv3x3_fwd", x.data_ptr(), cin, wf.data_ptr(), bias.data_ptr(), None, None, y.data_ptr(), cout,
-              stats.data_ptr(), n, h, w, cin, cout, d, BF, s)
+              stats.data_ptr(), None, n, h, w, cin, cout, d, BF, s)
 
 
 def app(s):

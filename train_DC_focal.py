@@ -13,6 +13,7 @@ best checkpoint reloaded, test loss / Dice / pixel accuracy, precision / recall 
 computed and printed; its PNG dumps and plots (:404-450, :468-611) are visualisation and out of scope.
 """
 import argparse
+import gc
 import os
 import time
 
@@ -21,7 +22,7 @@ from torch.utils.data import DataLoader, Subset
 
 from unet_dc_segmentation_amd import dp as dpmod
 from utils.data_loader import SegmentationDataset, SyntheticDropletDataset, TrainAugment
-from utils.metrics_DC import calculate_metrics, combined_loss, dice_coef, focal_dice_loss
+from utils.metrics_DC import combined_loss, dice_coef, focal_dice_loss, metrics_from_counts
 
 
 def build_parser(arch="unetdc", epochs=15, ckpt="best_UNetDC_focal_model.pth", loss="focal_dice"):
@@ -99,10 +100,7 @@ def evaluate_test(model, loader, criterion, device):
             cm_t += torch.stack([(~yp & ~yt).sum(), (yp & ~yt).sum(), (~yp & yt).sum(), (yp & yt).sum()])
     nb = max(1, len(loader))
     tn, fp, fn, tp = (int(v) for v in cm_t.tolist())
-    # calculate_metrics() takes label tensors; four run-length blocks reproduce the confusion matrix without moving the masks
-    y_true = torch.cat([torch.zeros(tn + fp), torch.ones(fn + tp)])
-    y_pred = torch.cat([torch.zeros(tn), torch.ones(fp), torch.zeros(fn), torch.ones(tp)])
-    precision, recall, f1, specificity, cm = calculate_metrics(y_true, y_pred)
+    precision, recall, f1, specificity, cm = metrics_from_counts(tn, fp, fn, tp)     # = calculate_metrics() on the label arrays
     total = max(1, tn + fp + fn + tp)
     return dict(test_loss=float(loss_t.item()) / nb, test_dice=float(dice_t.item()) / nb, test_acc=(tn + tp) / total,
                 precision=precision, recall=recall, f1=f1, specificity=specificity, confusion=cm.tolist())
@@ -155,6 +153,7 @@ def main(argv=None, parser=None):
               f"{world} rank(s), device {device}, compute {args.dtype}")
 
     best_dice, patience_counter = 0.0, 0
+    saved_this_run = False          # the final test evaluation only reloads a checkpoint THIS run wrote
     history = History()
     for epoch in range(args.epochs):
         model.train()
@@ -184,6 +183,13 @@ def main(argv=None, parser=None):
                 correct_t += (pred == masks).sum()
             total += masks.numel()
             seen += images.shape[0]
+            if epoch == 0 and step == 0:
+                # Everything alive after the first step (torch, the model, the engine's buffers and descriptor tables, the
+                # loader's workers) stays alive for the whole run: move it out of the cyclic collector's generations, so that
+                # the full collections Python triggers during training scan the few objects of the loop instead of torch's
+                # whole heap (a generation-2 pass there was measured at 40-60 ms: five training steps of host time).
+                gc.collect()
+                gc.freeze()
         nb = max(1, min(len(train_loader), args.steps or len(train_loader)))
         tr_loss, tr_dice, correct = float(tr_loss_t.item()), float(tr_dice_t.item()), int(correct_t.item())   # (waits for the epoch's work)
         dt = time.time() - t0
@@ -224,6 +230,7 @@ def main(argv=None, parser=None):
             print("-------------------------------------------------------")
         if rec["val_dice"] > best_dice:
             best_dice, patience_counter = rec["val_dice"], 0
+            saved_this_run = True       # (decided from rank 0's broadcast Dice: the same on every rank)
             if rank == 0:
                 torch.save(model.state_dict(), args.ckpt_path)
                 print("Model saved!")
@@ -236,8 +243,13 @@ def main(argv=None, parser=None):
     # -------- final test evaluation (train_DC_focal.py:365-402, :452-467): best checkpoint, held-out split --------
     if world > 1:
         torch.distributed.barrier()                         # rank 0 has finished writing the checkpoint
-    if args.test_eval and os.path.exists(args.ckpt_path) and len(test_ds) > 0:
-        model.load_state_dict(torch.load(args.ckpt_path, map_location=device, weights_only=True))
+    if args.test_eval and len(test_ds) > 0:
+        if saved_this_run and os.path.exists(args.ckpt_path):
+            model.load_state_dict(torch.load(args.ckpt_path, map_location=device, weights_only=True))
+        elif rank == 0:
+            # validation Dice never rose above 0: nothing was written by THIS run, and a file of that name left by an earlier
+            # run (possibly another architecture) is not this run's result
+            print(f"No checkpoint was written this run ({args.ckpt_path} not reloaded): evaluating the current weights")
         test_loader = DataLoader(test_ds, batch_size=args.batch, shuffle=False, num_workers=args.workers, pin_memory=pin)
         history.test = evaluate_test(model, test_loader, criterion, device)       # every rank: same weights, same split
         if rank == 0:
@@ -252,6 +264,7 @@ def main(argv=None, parser=None):
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    gc.unfreeze()                   # (a caller that runs main() in-process gets its objects back under the collector)
     return history
 
 

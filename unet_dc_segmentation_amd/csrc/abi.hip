@@ -3,6 +3,9 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <mutex>
+#include <vector>
+
 #include "../../include/unetdc_hip.h"
 #include "kernels.h"
 
@@ -29,6 +32,27 @@ int check_launch(const char* what) {
   return UNETDC_OK;
 }
 
+int ensure_dynamic_lds(const void* fn, int bytes, const char* name) {
+  struct Entry { const void* fn; int dev; int bytes; };
+  static std::mutex mu;
+  static std::vector<Entry> memo;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  Entry* hit = nullptr;
+  for (Entry& e : memo)
+    if (e.fn == fn && e.dev == dev) { hit = &e; break; }
+  if (hit && hit->bytes >= bytes) return UNETDC_OK;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    set_error("hipFuncSetAttribute(%s, %d bytes of LDS) failed on device %d: %s", name, bytes, dev, hipGetErrorString(e));
+    return UNETDC_ELAUNCH;
+  }
+  if (hit) hit->bytes = bytes;
+  else memo.push_back(Entry{fn, dev, bytes});
+  return UNETDC_OK;
+}
+
 static void taps3x3(int d, int* offy, int* offx) {
   for (int t = 0; t < 9; ++t) {
     offy[t] = (t / 3 - 1) * d;
@@ -48,8 +72,6 @@ extern "C" {
 int unetdc_version(void) { return UNETDC_ABI_VERSION; }
 const char* unetdc_last_error(void) { return g_err; }
 const char* unetdc_last_kernel(void) { return g_kernel; }
-static thread_local int g_stats_rows = 0;
-int unetdc_last_stats_rows(void) { return g_stats_rows; }
 
 int unetdc_pack_conv3x3(const float* w, void* w_fwd, void* w_dgrad, int cout, int cin, int dtype, unetdc_stream_t s) {
   return launch_pack_conv3x3(w, w_fwd, w_dgrad, cout, cin, dtype, (hipStream_t)s);
@@ -73,8 +95,8 @@ int unetdc_adam_step(const unetdc_adam_desc* table_dev, int n, int64_t total_blo
 int unetdc_conv3x3_stats_rows(int64_t npixels, int cout) { return igemm_mblocks((long)npixels, cout); }
 
 int unetdc_conv3x3_fwd(const void* x, int ldx, const void* w_fwd, const float* bias, const float* scale,
-                       const float* shift, void* y, int ldy, float* stats_part, int n, int h, int w, int cin,
-                       int cout, int dilation, int dtype, unetdc_stream_t s) {
+                       const float* shift, void* y, int ldy, float* stats_part, int* stats_rows, int n, int h, int w,
+                       int cin, int cout, int dilation, int dtype, unetdc_stream_t s) {
   GEOM_CHECK(n, h, w);
   UNETDC_REQUIRE(dilation >= 1, "conv3x3_fwd: dilation must be >= 1");
   UNETDC_REQUIRE(ldx >= cin && ldy >= cout, "conv3x3_fwd: ld smaller than channel count");
@@ -85,7 +107,7 @@ int unetdc_conv3x3_fwd(const void* x, int ldx, const void* w_fwd, const float* b
   p.mode = scale ? MODE_AFFINE_RELU : (stats_part ? MODE_STATS : MODE_STORE);
   taps3x3(dilation, p.offy, p.offx);
   const int rc = launch_igemm(p, dtype, (hipStream_t)s);
-  if (rc == UNETDC_OK && p.mode == MODE_STATS) g_stats_rows = p.mblocks;      // rows that carry data (the rest are zeros)
+  if (rc == UNETDC_OK && p.mode == MODE_STATS && stats_rows) *stats_rows = p.mblocks;   // rows that carry data (the rest are zeros)
   return rc;
 }
 
@@ -100,8 +122,8 @@ int unetdc_conv3x3_bnin_supported(int n, int h, int w, int cin, int cout, int di
 }
 
 int unetdc_conv3x3_fwd_bnin(const void* x_raw, int ldx, const float* in_scale, const float* in_shift, const void* w_fwd,
-                            const float* bias, void* y, int ldy, float* stats_part, int n, int h, int w, int cin, int cout,
-                            int dilation, int dtype, unetdc_stream_t s) {
+                            const float* bias, void* y, int ldy, float* stats_part, int* stats_rows, int n, int h, int w,
+                            int cin, int cout, int dilation, int dtype, unetdc_stream_t s) {
   GEOM_CHECK(n, h, w);
   UNETDC_REQUIRE(dilation >= 1 && ldx >= cin && ldy >= cout, "conv3x3_fwd_bnin: bad dilation/ld");
   UNETDC_REQUIRE(in_scale && in_shift && stats_part, "conv3x3_fwd_bnin: null pointer");
@@ -115,7 +137,7 @@ int unetdc_conv3x3_fwd_bnin(const void* x_raw, int ldx, const float* in_scale, c
     return UNETDC_EUNSUPPORTED;
   }
   const int rc = launch_igemm(p, dtype, (hipStream_t)s);
-  if (rc == UNETDC_OK) g_stats_rows = p.mblocks;
+  if (rc == UNETDC_OK && stats_rows) *stats_rows = p.mblocks;
   return rc;
 }
 

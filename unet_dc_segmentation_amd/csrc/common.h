@@ -26,6 +26,10 @@ namespace unetdc {
 
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+// hipFuncSetAttribute(fn, MaxDynamicSharedMemorySize, bytes) once per (device, kernel) -- the attribute belongs to the kernel
+// as loaded on ONE device, so the memo is keyed by the current device (a process that drives two GPUs sets it on both) and
+// raised again if a later call asks for more.  Returns UNETDC_OK or UNETDC_ELAUNCH (message in unetdc_last_error()).
+int ensure_dynamic_lds(const void* fn, int bytes, const char* name);
 void note_kernel(const char* name);          // records the symbol of the MFMA kernel just launched
 
 #define UNETDC_REQUIRE(cond, ...)                     \

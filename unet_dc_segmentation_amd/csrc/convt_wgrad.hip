@@ -179,9 +179,7 @@ static bool convt_wgrad_plan(int N, int H, int W, int CI, int CJ, int& ksplit, i
 }
 
 bool convt_wgrad_fused_supported(int N, int H, int W, int CI, int CJ, int ldx, int lddy, int dtype) {
-  static int off = -1;                            // UNETDC_CONVT_WGRAD=0: per-tap kernel (A/B)
-  if (off < 0) { const char* e = getenv("UNETDC_CONVT_WGRAD"); off = (e && e[0] == '0') ? 1 : 0; }
-  if (off || dtype != UNETDC_BF16) return false;
+  if (dtype != UNETDC_BF16) return false;
   int ks, sh;
   if (!convt_wgrad_plan(N, H, W, CI, CJ, ks, sh)) return false;
   const long P = (long)N * H * W;
@@ -206,15 +204,7 @@ int launch_convt_wgrad_fused(const void* x, int ldx, const void* dy, int lddy, f
   p.itiles = CI / 128;
   p.jtiles = CJ / 64;
   constexpr int LDS = 2 * CWG_HALF;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convt_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute(convt_wgrad_kernel) failed: %s", hipGetErrorString(e));
-      return UNETDC_ELAUNCH;
-    }
-    attr_done = true;
-  }
+  if (const int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&convt_wgrad_kernel), LDS, "convt_wgrad_kernel")) return rc_;
   *units_out = p.ksplit;
   const long nwg = (long)p.ksplit * p.itiles * p.jtiles;
   hipLaunchKernelGGL(convt_wgrad_kernel, dim3((unsigned)nwg), dim3(512), LDS, stream, p);

@@ -299,16 +299,7 @@ template <typename T, int WM, int WN>
 static int launch_cfg(IgemmParams& p, hipStream_t stream) {
   constexpr int BM = 64 * WM, BN = 64 * WN;
   constexpr int LDS = 2 * (BM + BN) * 128;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_conv_kernel<T, WM, WN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute(igemm_conv_kernel) failed: %s", hipGetErrorString(e));
-      return UNETDC_ELAUNCH;
-    }
-    attr_done = true;
-  }
+  if (const int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&igemm_conv_kernel<T, WM, WN>), LDS, "igemm_conv_kernel")) return rc_;
   p.mblocks = ceil_div(p.M, BM);
   p.nblocks = p.Cout / BN;
   const long nwg = (long)p.mblocks * p.nblocks;

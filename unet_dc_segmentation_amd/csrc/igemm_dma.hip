@@ -333,16 +333,7 @@ template <typename T, int WM, int WN, int TM>
 static int launch_dma_cfg(IgemmParams& p, hipStream_t stream) {
   constexpr int BM = WM * TM * 32, BN = WN * 64;
   constexpr int LDS = 2 * (BM + BN) * 128;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma_kernel<T, WM, WN, TM>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute(igemm_dma_kernel) failed: %s", hipGetErrorString(e));
-      return UNETDC_ELAUNCH;
-    }
-    attr_done = true;
-  }
+  if (const int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&igemm_dma_kernel<T, WM, WN, TM>), LDS, "igemm_dma_kernel")) return rc_;
   p.mblocks = ceil_div(p.M, BM);
   p.nblocks = p.Cout / BN;
   const long nwg = (long)p.mblocks * p.nblocks;

@@ -287,16 +287,7 @@ static int launch_dma16_cfg(IgemmParams& p, hipStream_t stream) {
   constexpr int BM = WM * TMT * 16, BN = WN * 64;
   constexpr int LDS = NS * (BM + BN) * 128;
   static_assert(LDS <= 160 * 1024, "ring does not fit");
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_dma16_kernel<WM, WN, TMT, NS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute(igemm_dma16_kernel) failed: %s", hipGetErrorString(e));
-      return UNETDC_ELAUNCH;
-    }
-    attr_done = true;
-  }
+  if (const int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&igemm_dma16_kernel<WM, WN, TMT, NS>), LDS, "igemm_dma16_kernel")) return rc_;
   p.mblocks = ceil_div(p.M, BM);
   p.nblocks = p.Cout / BN;
   // 16 x 16 pixel blocks as M tiles for strongly dilated 3 x 3 convolutions (header comment): every padded tap-pixel pair is skipped

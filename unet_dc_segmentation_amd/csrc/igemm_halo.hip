@@ -398,32 +398,15 @@ static int launch_halo_cfg(IgemmParams& p, int d, hipStream_t stream) {
   // config is alone on its CU, so it double-buffers the patch when there is more than one chunk
   const int nbuf = (WN == 2 && nkc > 1) ? 2 : 1;
   const int lds = nbuf * patch + 2 * (64 * WN) * 128;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo_kernel<T, WN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute(igemm_halo_kernel) failed: %s", hipGetErrorString(e));
-      return UNETDC_ELAUNCH;
-    }
-    attr_done = true;
-  }
+  if (const int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&igemm_halo_kernel<T, WN>), 160 * 1024, "igemm_halo_kernel")) return rc_;
   p.mblocks = (int)((long)p.M / 256);
   p.nblocks = p.Cout / (64 * WN);
   const long nwg = (long)p.mblocks * p.nblocks;
   const int rcp_pw = (65536 + (TW + 2 * d) - 1) / (TW + 2 * d);     // pr / PW == (pr * rcp_pw) >> 16 for pr < 1024 (PW <= 36)
   char nm[96];
   if (sizeof(T) == 2 && halo_mfma16()) {
-    static bool attr16 = false;
-    if (!attr16) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_halo16_kernel<WN>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) {
-        set_error("hipFuncSetAttribute(igemm_halo16_kernel) failed: %s", hipGetErrorString(e));
-        return UNETDC_ELAUNCH;
-      }
-      attr16 = true;
-    }
+    if (const int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&igemm_halo16_kernel<WN>), 160 * 1024, "igemm_halo16_kernel"))
+      return rc_;
     hipLaunchKernelGGL((igemm_halo16_kernel<WN>), dim3((unsigned)nwg), dim3(256 * WN), lds, stream, p, d, nbuf, rcp_pw);
     snprintf(nm, sizeof(nm), "igemm_halo16_kernel<%d>", WN);
     note_kernel(nm);

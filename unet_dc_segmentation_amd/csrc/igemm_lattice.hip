@@ -896,16 +896,7 @@ static int launch_lattice_cfg(IgemmParams& p, const LatticeParams& q, int wgs_pe
   constexpr int NW = WM * WN, BN = WN * 64;
   constexpr int PJ = (LPI + NW - 1) / NW;
   constexpr int LDS = NPB * PJ * NW * 1024 + 3 * BN * 128 + NW * 128 * 4 + (INORM ? 2048 : 0);   // INORM: + [2][Cin <= 256] constants
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_lattice_kernel<WM, WN, MT, NPB, MODE, INORM>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute(igemm_lattice_kernel) failed: %s", hipGetErrorString(e));
-      return UNETDC_ELAUNCH;
-    }
-    attr_done = true;
-  }
+  if (const int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&igemm_lattice_kernel<WM, WN, MT, NPB, MODE, INORM>), LDS, "igemm_lattice_kernel")) return rc_;
   // persistent grid: as many workgroups as fit the chip at once (256 CUs), never more than there are items
   const long grid = lattice_grid(q.items, wgs_per_cu);
   if (grid % q.nblocks != 0 || q.stat_rows != (int)(grid / q.nblocks)) {
@@ -923,16 +914,7 @@ template <int MODE>
 static int launch_lattice_wide_cfg(IgemmParams& p, const LatticeParams& q, hipStream_t stream) {
   constexpr int NW = 4, BN = 128, PJ = (LPI + NW - 1) / NW;
   constexpr int LDS = PJ * NW * 1024 + 2 * BN * 128 + NW * 2 * 128 * 4;       // 44 KB patch + 2 x 16 KB weights + 4 KB scratch = 80 KB
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_lattice_wide_kernel<MODE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute(igemm_lattice_wide_kernel) failed: %s", hipGetErrorString(e));
-      return UNETDC_ELAUNCH;
-    }
-    attr_done = true;
-  }
+  if (const int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&igemm_lattice_wide_kernel<MODE>), LDS, "igemm_lattice_wide_kernel")) return rc_;
   const long grid = lattice_grid(q.items, 2);
   if (grid % q.nblocks != 0 || q.stat_rows != (int)(grid / q.nblocks)) {
     set_error("igemm_lattice_wide: grid %ld / nblocks %d / stat_rows %d inconsistent", grid, q.nblocks, q.stat_rows);

@@ -306,16 +306,7 @@ long wgrad_workspace_bytes(long P, int CI, int CJ, int ntaps, int dtype) {
 
 template <typename T, int TW>
 static int launch_w(WgradParams& p, hipStream_t stream) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, TW>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute(wgrad_kernel) failed: %s", hipGetErrorString(e));
-      return UNETDC_ELAUNCH;
-    }
-    attr_done = true;
-  }
+  if (const int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&wgrad_kernel<T, TW>), 65536, "wgrad_kernel")) return rc_;
   const long nwg = (long)p.ksplit * p.ntaps * p.itiles * p.jtiles;
   hipLaunchKernelGGL((wgrad_kernel<T, TW>), dim3((unsigned)nwg), dim3(256), 65536, stream, p);
   char nm[96];

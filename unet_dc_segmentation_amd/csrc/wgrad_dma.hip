@@ -179,16 +179,7 @@ template <typename T, int TW>
 static int launch_wd(WgradParams& p, hipStream_t stream) {
   constexpr int LDS = (TW == 4) ? 131072 : 65536;
   constexpr int NT = (TW == 4) ? 512 : 256;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_dma_kernel<T, TW>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute(wgrad_dma_kernel) failed: %s", hipGetErrorString(e));
-      return UNETDC_ELAUNCH;
-    }
-    attr_done = true;
-  }
+  if (const int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&wgrad_dma_kernel<T, TW>), LDS, "wgrad_dma_kernel")) return rc_;
   const long nwg = (long)p.ksplit * p.ntaps * p.itiles * p.jtiles;
   hipLaunchKernelGGL((wgrad_dma_kernel<T, TW>), dim3((unsigned)nwg), dim3(NT), LDS, stream, p);
   char nm[96];

@@ -981,12 +981,9 @@ int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* 
   // PAIRED FORM (round 4): 512-thread workgroups whose two halves walk the two halves of a unit's rows and meet in LDS
   // (split_finish): half as many fp32 slabs written and reduced.  The plan is the one above at a target of 256 workgroups
   // (one per CU: the two rings fill the LDS), i.e. every half does exactly the work a 256-thread workgroup did.
-  // UNETDC_WGRAD_PAIR=0: unpaired form (A/B).
-  static int pair = -1;
-  if (pair < 0) { const char* e = getenv("UNETDC_WGRAD_PAIR"); pair = (e && e[0] == '0') ? 0 : 1; }
   // (three-segment staging, d = 4 / 8, waits for ALL its DMAs at every step: in lock step the two halves expose that wait
   //  together -- measured 155.4 vs 157.9 us at d = 4 but 175.3 vs 166.3 us at d = 8, profiles/r04_wgrad_pair_ab.txt)
-  if (pair && dtype == UNETDC_BF16 && split && (pf || d <= 4)) {
+  if (dtype == UNETDC_BF16 && split && (pf || d <= 4)) {
     const int strips = N * (W / fused_seg(dtype)), tiles = p.itiles * p.jtiles;
     int ys = 256 / (strips * tiles);
     if (ys < 1) ys = 1;
@@ -1015,18 +1012,7 @@ int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* 
                                        : reinterpret_cast<const void*>(&wgrad_ring_split_kernel<1, true, true, 2>);
       else fn2 = pf == 2 ? reinterpret_cast<const void*>(&wgrad_ring_split_kernel<2, true, false, 2>)
                          : reinterpret_cast<const void*>(&wgrad_ring_split_kernel<1, true, false, 2>);
-      static const void* attr_set[8] = {nullptr};
-      bool have = false;
-      for (int i = 0; i < 8; ++i) have = have || attr_set[i] == fn2;
-      if (!have) {
-        hipError_t e = hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
-        if (e != hipSuccess) {
-          set_error("hipFuncSetAttribute(paired wgrad kernel) failed: %s", hipGetErrorString(e));
-          return UNETDC_ELAUNCH;
-        }
-        for (int i = 0; i < 8; ++i)
-          if (!attr_set[i]) { attr_set[i] = fn2; break; }
-      }
+      if (const int rc_ = ensure_dynamic_lds(fn2, lds2, "paired wgrad kernel")) return rc_;
       *units_out = un;
       const dim3 g((unsigned)nwg2), b(512);
       if (!pf) hipLaunchKernelGGL((wgrad_fused_split_kernel<true, 2>), g, b, lds2, stream, q);
@@ -1052,27 +1038,11 @@ int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* 
     }
     const void* fn = pf == 2 ? reinterpret_cast<const void*>(&wgrad_ring_split_kernel<2, true>)
                              : reinterpret_cast<const void*>(&wgrad_ring_split_kernel<1, true>);
-    static bool split_attr[3] = {false, false, false};
-    if (!split_attr[pf]) {
-      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      if (e != hipSuccess) {
-        set_error("hipFuncSetAttribute(wgrad_ring_split_kernel) failed: %s", hipGetErrorString(e));
-        return UNETDC_ELAUNCH;
-      }
-      split_attr[pf] = true;
-    }
+    if (const int rc_ = ensure_dynamic_lds(fn, 80 * 1024, "wgrad_ring_split_kernel")) return rc_;
     if (in_scale) {
-      static bool nattr[3] = {false, false, false};
       const void* nfn = pf == 2 ? reinterpret_cast<const void*>(&wgrad_ring_split_kernel<2, true, true>)
                                 : reinterpret_cast<const void*>(&wgrad_ring_split_kernel<1, true, true>);
-      if (!nattr[pf]) {
-        hipError_t e = hipFuncSetAttribute(nfn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        if (e != hipSuccess) {
-          set_error("hipFuncSetAttribute(wgrad_ring_split_kernel bnin) failed: %s", hipGetErrorString(e));
-          return UNETDC_ELAUNCH;
-        }
-        nattr[pf] = true;
-      }
+      if (const int rc_ = ensure_dynamic_lds(nfn, 96 * 1024, "wgrad_ring_split_kernel bnin")) return rc_;
       if (pf == 2) hipLaunchKernelGGL((wgrad_ring_split_kernel<2, true, true>), dim3((unsigned)nwg), dim3(256), lds, stream, p);
       else hipLaunchKernelGGL((wgrad_ring_split_kernel<1, true, true>), dim3((unsigned)nwg), dim3(256), lds, stream, p);
       note_kernel(pf == 2 ? "wgrad_ring_split_kernel<2, 16x16x32> bnin" : "wgrad_ring_split_kernel<1, 16x16x32> bnin");
@@ -1090,15 +1060,7 @@ int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* 
                                             : reinterpret_cast<const void*>(&wgrad_ring_kernel<bf16_t, 1>);
     else fn = pf == 2 ? reinterpret_cast<const void*>(&wgrad_ring_kernel<float, 2>)
                       : reinterpret_cast<const void*>(&wgrad_ring_kernel<float, 1>);
-    static bool ring_attr[2][3] = {{false, false, false}, {false, false, false}};
-    if (!ring_attr[dtype][pf]) {
-      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      if (e != hipSuccess) {
-        set_error("hipFuncSetAttribute(wgrad_ring_kernel) failed: %s", hipGetErrorString(e));
-        return UNETDC_ELAUNCH;
-      }
-      ring_attr[dtype][pf] = true;
-    }
+    if (const int rc_ = ensure_dynamic_lds(fn, 80 * 1024, "wgrad_ring_kernel")) return rc_;
     if (dtype == UNETDC_BF16) {
       if (pf == 2) hipLaunchKernelGGL((wgrad_ring_kernel<bf16_t, 2>), dim3((unsigned)nwg), dim3(256), lds, stream, p);
       else hipLaunchKernelGGL((wgrad_ring_kernel<bf16_t, 1>), dim3((unsigned)nwg), dim3(256), lds, stream, p);
@@ -1115,31 +1077,15 @@ int launch_wgrad_fused(const void* dy, int lddy, const void* x, int ldx, float* 
   const int seg = fused_seg(dtype);
   const int lds = 2 * (seg * 64 * es + 3 * (seg + 16) * 64 * es);
   if (dtype == UNETDC_BF16 && split) {                   // d = 4, 8 in bf16: tap-split wave roles on the three-segment staging
-    static bool sattr = false;
-    if (!sattr) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_fused_split_kernel<true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      if (e != hipSuccess) {
-        set_error("hipFuncSetAttribute(wgrad_fused_split_kernel) failed: %s", hipGetErrorString(e));
-        return UNETDC_ELAUNCH;
-      }
-      sattr = true;
-    }
+    if (const int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&wgrad_fused_split_kernel<true>), lds, "wgrad_fused_split_kernel"))
+      return rc_;
     hipLaunchKernelGGL(wgrad_fused_split_kernel<true>, dim3((unsigned)nwg), dim3(256), lds, stream, p);
     note_kernel("wgrad_fused_split_kernel<16x16x32>");
     return check_launch("wgrad_fused_split_kernel");
   }
-  static bool attr_done[2] = {false, false};
   const void* fn = dtype == UNETDC_BF16 ? reinterpret_cast<const void*>(&wgrad_fused_kernel<bf16_t>)
                                         : reinterpret_cast<const void*>(&wgrad_fused_kernel<float>);
-  if (!attr_done[dtype]) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute(wgrad_fused_kernel) failed: %s", hipGetErrorString(e));
-      return UNETDC_ELAUNCH;
-    }
-    attr_done[dtype] = true;
-  }
+  if (const int rc_ = ensure_dynamic_lds(fn, lds, "wgrad_fused_kernel")) return rc_;
   if (dtype == UNETDC_BF16)
     hipLaunchKernelGGL(wgrad_fused_kernel<bf16_t>, dim3((unsigned)nwg), dim3(256), lds, stream, p);
   else

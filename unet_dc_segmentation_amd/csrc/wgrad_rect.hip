@@ -228,16 +228,7 @@ int launch_wgrad_rect(const void* dy, int lddy, const void* x, int ldx, float* o
     set_error("wgrad_rect: workspace too small (%ld < %ld bytes)", workspace_bytes, need);
     return UNETDC_EWORKSPACE;
   }
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_rect_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    if (e != hipSuccess) {
-      set_error("hipFuncSetAttribute(wgrad_rect_kernel) failed: %s", hipGetErrorString(e));
-      return UNETDC_ELAUNCH;
-    }
-    attr_done = true;
-  }
+  if (const int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&wgrad_rect_kernel), 131072, "wgrad_rect_kernel")) return rc_;
   const long nwg = (long)nu * p.itiles * p.jtiles;
   hipLaunchKernelGGL(wgrad_rect_kernel, dim3((unsigned)nwg), dim3(512), 131072, stream, p);
   note_kernel("wgrad_rect_kernel");

@@ -50,6 +50,8 @@ class DataParallel:
         self._pending = None            # (flat, lo, hi) not yet launched
         self._flat = None
         self.stats = {"buckets": 0, "elems": 0, "steps": 0}
+        self._trace = None              # per-step timeline records while start_trace() ... stop_trace() (bench.py, after its timed region)
+        self._probe = None              # side stream that only waits for collectives and records their completion events
         if broadcast:
             self.broadcast_state()
         model.grad_ready_hook = self._on_ready
@@ -95,14 +97,88 @@ class DataParallel:
     def _launch_one(self, flat, lo, hi):
         view = flat[lo:hi]
         self.schedule.append(hi - lo)
+        rec = self._trace_bucket(flat, hi - lo) if self._trace is not None else None
         if self.backend == "nccl":
             work = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
-            self._works.append((work, None))
+            self._works.append((work, None, rec))
         else:  # gloo has no AVG
             work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-            self._works.append((work, view))
+            self._works.append((work, view, rec))
+        if rec is not None and rec["device"]:
+            # completion time of THIS collective: a side stream that does nothing but wait for it (Work.wait() makes the
+            # current stream wait for RCCL's stream) and record an event -- the compute stream is not touched
+            with torch.cuda.stream(self._probe):
+                work.wait()
+                rec["done"].record()
         self.stats["buckets"] += 1
         self.stats["elems"] += hi - lo
+
+    # -------------------------------------------------------------- timeline of the exchange (instrumented passes only)
+    def start_trace(self):
+        """Record, for every step until stop_trace(): when each bucket became ready (all its producers enqueued: an event
+        on the compute stream), when its all-reduce completed (an event on a probe stream behind RCCL's), and how long the
+        compute stream stood waiting in finish() (= the EXPOSED part of the exchange).  Device events with RCCL on HIP
+        tensors; host perf_counter stamps otherwise (gloo: Work.wait() blocks the host)."""
+        self._trace = []
+
+    def mark_step_start(self):
+        """Optional: the zero of the per-bucket times (default: the first ready range of the step)."""
+        if self._trace is not None:
+            self._trace.append(dict(self._new_step_record(None), marked=True))
+
+    def _new_step_record(self, flat):
+        import time
+        device = self.backend == "nccl" and torch.cuda.is_available()
+        rec = {"device": device, "buckets": [], "fin": None, "closed": False}
+        if device:
+            if self._probe is None:
+                self._probe = torch.cuda.Stream()
+            rec["t0"] = torch.cuda.Event(enable_timing=True)
+            rec["t0"].record()
+        else:
+            rec["t0"] = time.perf_counter()
+        return rec
+
+    def _trace_bucket(self, flat, elems):
+        import time
+        if not self._trace or self._trace[-1]["closed"]:
+            self._trace.append(self._new_step_record(flat))
+        step = self._trace[-1]
+        b = {"elems": elems, "device": step["device"]}
+        if step["device"]:
+            b["ready"], b["done"] = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            b["ready"].record()
+        else:
+            b["ready"], b["done"] = time.perf_counter(), None
+        step["buckets"].append(b)
+        return b
+
+    def stop_trace(self):
+        """-> {"exposed_ms_per_step", "buckets": [{"MB", "ready_at_ms", "done_at_ms"}], "traced_steps", "clock"} averaged over
+        the traced steps (bucket k of every step is the same slice: the schedule is static)."""
+        trace, self._trace = self._trace, None
+        if not trace:
+            return None
+        device = trace[0]["device"]
+        if device:
+            torch.cuda.synchronize()
+        steps = [t for t in trace if t["closed"] and t["buckets"]]
+        if not steps:
+            return None
+        ms = (lambda a, b: a.elapsed_time(b)) if device else (lambda a, b: (b - a) * 1e3)
+        nb = min(len(t["buckets"]) for t in steps)
+        out = {"traced_steps": len(steps),
+               "clock": "HIP events (compute stream / probe stream behind RCCL's)" if device else "host perf_counter (blocking backend)",
+               "exposed_ms_per_step": sum(ms(*t["fin"]) for t in steps) / len(steps),
+               "zero": "mark_step_start() (= start of the step's forward)" if "marked" in steps[0] else "first ready range of the step",
+               "buckets": []}
+        for k in range(nb):
+            out["buckets"].append({
+                "MB": steps[0]["buckets"][k]["elems"] * 4 / 1e6,
+                "ready_at_ms": sum(ms(t["t0"], t["buckets"][k]["ready"]) for t in steps) / len(steps),
+                "done_at_ms": sum(ms(t["t0"], t["buckets"][k]["done"]) for t in steps) / len(steps)})
+        out["last_done_after_backward_ms"] = sum(ms(t["fin"][0], t["buckets"][nb - 1]["done"]) for t in steps) / len(steps)
+        return out
 
     def _on_ready(self, flat, lo, hi):
         """Called by the backward schedule: gradients flat[lo:hi] are enqueued on the compute stream."""
@@ -121,13 +197,28 @@ class DataParallel:
 
     def finish(self):
         """Flush the last bucket and make the compute stream wait for every collective."""
+        import time
         if self._pending is not None:
             self._launch(*self._pending)
             self._pending = None
-        for work, view in self._works:
+        step = self._trace[-1] if self._trace else None
+        if step is not None and step["closed"]:
+            step = None
+        if step is not None:
+            f0 = torch.cuda.Event(enable_timing=True) if step["device"] else time.perf_counter()
+            if step["device"]:
+                f0.record()
+        for work, view, rec in self._works:
             work.wait()
+            if rec is not None and not rec["device"]:
+                rec["done"] = time.perf_counter()
             if view is not None:
                 view.div_(self.world)
+        if step is not None:
+            f1 = torch.cuda.Event(enable_timing=True) if step["device"] else time.perf_counter()
+            if step["device"]:
+                f1.record()
+            step["fin"], step["closed"] = (f0, f1), True
         self._works.clear()
         self.stats["steps"] += 1
 

@@ -23,18 +23,22 @@ Data layout in HBM
 """
 from __future__ import annotations
 
+import ctypes
+import os
+
 import torch
 
 from . import _lib
 from ._lib import call
 
-import os
+_byref = ctypes.byref
+# references to a tensor's storage (tensor + views + Python wrappers); absent on a torch build without it: allocate per step
+_storage_use_count = getattr(torch._C, "_storage_Use_Count", None)
 
 ENCODER = ("enc1", "enc2", "enc3", "enc4")
-# fuse the BatchNorm-backward reduction into the dgrad epilogue that produces the gradient (A/B switch)
+# fuse the BatchNorm-backward reduction into the dgrad epilogue that produces the gradient (A/B switch; the stand-alone
+# reduction is also the fallback of the first-generation kernels)
 FUSE_BN_BWD = os.environ.get("UNETDC_FUSE_BNBWD", "1") != "0"
-# ConvTranspose2d bias gradient = column sums of the concat gradient, produced by the dgrad epilogue that writes it
-FUSE_COLSUM = os.environ.get("UNETDC_FUSE_COLSUM", "1") != "0"
 # The head reads dec1's RAW conv output and applies that stage's BatchNorm + ReLU on load (unetdc_head_fwd_bn; the backward
 # recomputes the activation the same way): dec1.3's normalisation pass and its 268 MB activation tensor disappear from the
 # training step.  UNETDC_FUSE_HEAD_BN=0: stand-alone pass (A/B switch)
@@ -44,14 +48,12 @@ FUSE_HEAD_BN = os.environ.get("UNETDC_FUSE_HEAD_BN", "1") != "0" and FUSE_BN_BWD
 # that stage's normalisation pass and activation tensor disappear.  Used where the library has the kernels (bf16, 64-channel
 # blocks: enc1 and dec1, the two largest normalisation passes of the step).  UNETDC_FUSE_BNIN=0: stand-alone passes (A/B)
 FUSE_BNIN = os.environ.get("UNETDC_FUSE_BNIN", "1") != "0"
-# One-channel head (the networks' configuration): the gradient of the head's input is dz * w[c] per pixel, so dec1's last stage
-# recomputes it in its BatchNorm-backward pass (unetdc_bn_relu_bwd_head) instead of reading a tensor the head backward wrote:
-# 2 x 268 MB less traffic per step at 8 x 512 x 512, bit-identical.  UNETDC_FUSE_HEAD_BWD=0: stored form (A/B).
-FUSE_HEAD_BWD = os.environ.get("UNETDC_FUSE_HEAD_BWD", "1") == "1"
-# First stage (enc1.0, one input channel): its weight gradient applies the stage's BatchNorm + ReLU backward on load
-# (unetdc_conv3x3_first_wgrad_bn) -- nothing else reads that stage's dy unless dL/dx is asked for, so the pass that writes it
-# (3 x 268 MB of traffic at 8 x 512 x 512) is not run.  Bit-identical.  UNETDC_FUSE_FIRST_BN=0: two-pass form (A/B).
-FUSE_FIRST_BN = os.environ.get("UNETDC_FUSE_FIRST_BN", "1") == "1"
+# Settled in rounds 3-4 (bit-identical to the forms they replaced, which are gone from the schedule):
+#  * the ConvTranspose2d bias gradient = column sums of the concat gradient, produced by the dgrad epilogue that writes it;
+#  * one-channel head: the gradient of the head's input is dz * w[c] per pixel, so dec1's last stage recomputes it in its
+#    BatchNorm-backward pass (unetdc_bn_relu_bwd_head) instead of reading a tensor the head backward wrote;
+#  * first stage (enc1.0): its weight gradient applies the stage's BatchNorm + ReLU backward on load
+#    (unetdc_conv3x3_first_wgrad_bn) -- nothing else reads that stage's dy unless dL/dx is asked for.
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
@@ -291,6 +293,8 @@ class UNetEngine:
         # backward has run or its graph has been freed); the module gives another forward of this shape its own engine meanwhile
         self.busy = False
         self._busy_gen = -1
+        self._rows, self._np = ctypes.c_int(0), ctypes.c_int(0)      # out-parameters of the C ABI (statistics rows that carry data)
+        self._flat = None              # flat fp32 gradient buffer, kept across steps (see _flat_grads)
 
     # ------------------------------------------------------------------ weight caches
     def invalidate_weight_cache(self):
@@ -327,18 +331,18 @@ class UNetEngine:
             y = st.y
             if bnin is not None:                   # xin = the RAW output of the stage in front, normalised per staged patch
                 call("unetdc_conv3x3_fwd_bnin", xin.data_ptr(), xin.stride(0), bnin[0].data_ptr(), bnin[1].data_ptr(),
-                     st.w_fwd.data_ptr(), conv.bias.data_ptr(), y.data_ptr(), y.stride(0), st.stats.data_ptr(), N, h, w,
-                     st.cin, st.cout, st.dil, self.dt, s)
-                st.stat_rows = _lib.load().unetdc_last_stats_rows()
+                     st.w_fwd.data_ptr(), conv.bias.data_ptr(), y.data_ptr(), y.stride(0), st.stats.data_ptr(), _byref(self._rows),
+                     N, h, w, st.cin, st.cout, st.dil, self.dt, s)
+                st.stat_rows = self._rows.value
             elif st.first:
                 call("unetdc_conv3x3_first_fwd", xin.data_ptr(), conv.weight.data_ptr(), conv.bias.data_ptr(),
                      None, None, y.data_ptr(), y.stride(0), st.stats.data_ptr(), N, h, w, st.cin, st.cout,
                      st.dil, self.dt, s)
             else:
                 call("unetdc_conv3x3_fwd", xin.data_ptr(), xin.stride(0), st.w_fwd.data_ptr(), conv.bias.data_ptr(),
-                     None, None, y.data_ptr(), y.stride(0), st.stats.data_ptr(), N, h, w, st.cin, st.cout,
-                     st.dil, self.dt, s)
-                st.stat_rows = _lib.load().unetdc_last_stats_rows()     # rows that carry data (<= the sizing bound)
+                     None, None, y.data_ptr(), y.stride(0), st.stats.data_ptr(), _byref(self._rows), N, h, w, st.cin,
+                     st.cout, st.dil, self.dt, s)
+                st.stat_rows = self._rows.value                         # rows that carry data (<= the sizing bound)
             track = bn.track_running_stats and bn.running_mean is not None
             mom = BN_MOMENTUM if bn.momentum is None else bn.momentum
             if frozen and track:
@@ -366,7 +370,7 @@ class UNetEngine:
                      self.dt, s)
             else:
                 call("unetdc_conv3x3_fwd", xin.data_ptr(), xin.stride(0), st.w_fwd.data_ptr(), None,
-                     st.scale.data_ptr(), st.shift.data_ptr(), dst.data_ptr(), dst.stride(0), None, N, h, w,
+                     st.scale.data_ptr(), st.shift.data_ptr(), dst.data_ptr(), dst.stride(0), None, None, N, h, w,
                      st.cin, st.cout, st.dil, self.dt, s)
             if pooled is not None:
                 call("unetdc_bn_relu_apply", dst.data_ptr(), dst.stride(0), None, None, None, 0,
@@ -444,6 +448,19 @@ class UNetEngine:
         self.grad_bufs = g
         self.workspace = torch.empty(self.ws_bytes, device=dev, dtype=torch.uint8)
 
+    def _flat_grads(self):
+        """The flat fp32 gradient buffer of this backward (124 MB for the U-Net-DC).  ONE buffer is kept per engine and handed
+        out again when nothing but the engine still refers to its storage -- the usual training loop, where zero_grad() has
+        dropped the previous step's ``.grad`` views (train_DC_focal.py:251) -- so that a step never goes back to the caching
+        allocator for its largest block.  While anything still views it (gradient accumulation without zero_grad, gradients
+        kept by the caller, torch.autograd.grad results) a fresh buffer is allocated instead and becomes the kept one:
+        gradients handed out are never overwritten by a later backward."""
+        f = self._flat
+        if f is not None and _storage_use_count is not None and _storage_use_count(f.untyped_storage()._cdata) <= 2:
+            return f                   # 2 = this tensor + the Python storage wrapper of the query
+        self._flat = torch.empty(self.nparams, device=self.device, dtype=torch.float32)
+        return self._flat
+
     def _gview(self, flat, p):
         i = self.pindex[id(p)]
         return flat[self.poffs[i]: self.poffs[i] + p.numel()]
@@ -452,10 +469,9 @@ class UNetEngine:
         """Arguments describing the stage whose BN-backward reduction a dgrad epilogue should fuse."""
         if prev.bwd_parts is None:
             prev.bwd_parts = torch.empty((prev.bwd_rows + 64) * 3 * prev.cout, device=self.device, dtype=torch.float32)
-        self._np = getattr(self, "_np", None) or __import__("ctypes").c_int(0)
         return (prev.y.data_ptr(), prev.y.stride(0), prev.scale.data_ptr(), prev.shift.data_ptr(),
                 prev.mean.data_ptr(), prev.rstd.data_ptr(), prev.bwd_parts.data_ptr(), prev.bwd_parts.numel(),
-                __import__("ctypes").byref(self._np))
+                _byref(self._np))
 
     def _stage_bwd(self, st, flat, lvl, dskip, dpool, dx_out, fuse_prev=None, colsum=None, head=None):
         """Backward of one stage.  dskip/dpool: incoming gradient(s) of the activation;
@@ -470,7 +486,7 @@ class UNetEngine:
         dy = st.dy
         ws, wsb = self.workspace.data_ptr(), self.ws_bytes
         pre = (st.bwd_parts.data_ptr(), st.bwd_nparts) if (st.bwd_nparts and dpool is None) else (None, 0)
-        if (st.first and FUSE_FIRST_BN and pre[0] is not None and dskip is not None and not self._frozen
+        if (st.first and pre[0] is not None and dskip is not None and not self._frozen
               and not getattr(self, "_need_dx", False)
               and _lib.load().unetdc_conv3x3_first_wgrad_bn_supported(N, h, w, st.cin, st.cout, st.dil, self.dt)):
             # BatchNorm backward of the first stage on load of its weight gradient: dy is never written
@@ -532,7 +548,7 @@ class UNetEngine:
                      dx_out.data_ptr(), dx_out.stride(0), *self._bnstats_args(fuse_prev), N, h, w, st.cin, st.cout,
                      st.dil, self.dt, s)
                 fuse_prev.bwd_nparts = self._np.value
-            elif dx_out is not None and colsum is not None and FUSE_COLSUM:
+            elif dx_out is not None and colsum is not None:
                 call("unetdc_conv3x3_dgrad_colsum", dy.data_ptr(), dy.stride(0), st.w_dgrad.data_ptr(), dx_out.data_ptr(),
                      dx_out.stride(0), colsum[0].data_ptr(), colsum[1], colsum[2], ws, wsb, N, h, w, st.cin, st.cout,
                      st.dil, self.dt, s)
@@ -577,13 +593,13 @@ class UNetEngine:
         N = self.N
         g = self.grad_bufs
         ws, wsb = self.workspace.data_ptr(), self.ws_bytes
-        flat = torch.empty(self.nparams, device=self.device, dtype=torch.float32)
+        flat = self._flat_grads()
         dprobs = dprobs.contiguous()
         oc = self.model.out_conv
         da = g[("da", 0)]
         last = self.stages[("dec1", 3)]                  # its activated output feeds out_conv
-        # one output channel, training statistics: the head's input gradient is never stored (see FUSE_HEAD_BWD)
-        head = (dprobs, probs, oc.weight) if (FUSE_BN_BWD and FUSE_HEAD_BWD and self.oc == 1 and not self._frozen) else None
+        # one output channel, training statistics: the head's input gradient is never stored (dec1.3 recomputes it)
+        head = (dprobs, probs, oc.weight) if (FUSE_BN_BWD and self.oc == 1 and not self._frozen) else None
         if FUSE_BN_BWD:                                  # da's BatchNorm-backward sums come out of the same pass
             call("unetdc_head_bwd_bnstats", dprobs.data_ptr(), probs.data_ptr(), _ptr(self.head_in),
                  self.head_in.stride(0) if self.head_in is not None else 64, oc.weight.data_ptr(),
@@ -612,9 +628,6 @@ class UNetEngine:
             xin = u["x_in"]
             call("unetdc_convT2x2_wgrad", xin.data_ptr(), xin.stride(0), dup.data_ptr(), dup.stride(0),
                  self._gview(flat, u["mod"].weight).data_ptr(), ws, wsb, N, h, w, u["cin"], c, self.dt, s)
-            if not FUSE_COLSUM:
-                call("unetdc_channel_sum", dup.data_ptr(), dup.stride(0), self._gview(flat, u["mod"].bias).data_ptr(),
-                     ws, wsb, self.npix[l], c, self.dt, s)
             dnext = g[("da", lvl)]               # gradient w.r.t. the up-conv input (level lvl+1 resolution)
             prev = self.stages[("bottleneck" if lvl == 4 else f"dec{lvl + 1}", 3)]     # producer of the up-conv input
             if FUSE_BN_BWD:

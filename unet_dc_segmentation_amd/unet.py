@@ -99,6 +99,7 @@ class _UNetFamily(nn.Module):
                 if victim is None:
                     extra = next((e for e in pool if e is not eng and not e.busy), None)
                     if extra is None:
+                        self._warn_live_graphs(sum(len(v) for v in self._engines.values()) + len(pool), eng)
                         break
                     pool.remove(extra)
                     continue
@@ -110,6 +111,22 @@ class _UNetFamily(nn.Module):
             pool.append(eng)                           # most recently used last
         self._engines[key] = pool
         return eng
+
+    def _warn_live_graphs(self, live, eng):
+        """Every engine is held by a live autograd graph and the pool is past MAX_ENGINES: say so once -- a caller that keeps
+        outputs with gradients enabled (predictions collected in a list without torch.no_grad()) otherwise runs the device out
+        of memory with an error that names nothing."""
+        if getattr(self, "_warned_live", False):
+            return
+        self._warned_live = True
+        import warnings
+        per = sum(t.numel() * t.element_size() for t in
+                  [st.y for st in eng.stages.values()] + list(eng.a0.values()) + list(eng.a3.values())
+                  + list(eng.cat.values()) + list(eng.pool.values())) / 2 ** 30
+        warnings.warn(f"{type(self).__name__}: {live} forwards of this module are alive at once (each keeps ~{per:.1f} GiB of "
+                      f"activations for its backward; only {self.MAX_ENGINES} sets are kept for re-use).  If no backward is "
+                      "meant to follow, run the forward under torch.no_grad(); otherwise call backward() (or drop the "
+                      "outputs) before starting further forwards.", RuntimeWarning, stacklevel=4)
 
     def __getstate__(self):
         """copy.deepcopy / pickling (torch.save(model)) carry the module, not the device-side engines: activation buffers,

@@ -78,6 +78,13 @@ def calculate_metrics(y_true, y_pred):
     yt = (y_true.reshape(-1).cpu().numpy() > 0.5)
     tp = int(np.sum(yp & yt)); fp = int(np.sum(yp & ~yt))
     fn = int(np.sum(~yp & yt)); tn = int(np.sum(~yp & ~yt))
+    return metrics_from_counts(tn, fp, fn, tp)
+
+
+def metrics_from_counts(tn, fp, fn, tp):
+    """calculate_metrics() from the four cells of the confusion matrix (callers that counted on the device, e.g. the final test
+    evaluation of train_DC_focal.py, need no per-pixel label arrays on the host)."""
+    tn, fp, fn, tp = int(tn), int(fp), int(fn), int(tp)
     precision = tp / (tp + fp) if tp + fp > 0 else 1.0
     recall = tp / (tp + fn) if tp + fn > 0 else 1.0
     # sklearn's f1_score(zero_division=1): 1.0 when there are no positives at all, 0.0 when only p + r == 0
