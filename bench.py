@@ -455,8 +455,11 @@ def _pct(sorted_vals, q):
     return sorted_vals[min(len(sorted_vals) - 1, max(0, int(round(q * (len(sorted_vals) - 1)))))]
 
 
-def timed_region(step, steps, make_event=None, sync=None, barrier=None, alloc_stats=None):
-    """The timed region and NOTHING else: `steps` calls of step() between barrier + device sync on both sides.
+def timed_region(step, steps, make_event=None, sync=None, barrier=None, alloc_stats=None, warmup=0):
+    """`warmup` untimed calls of step(), then the timed region and NOTHING else: `steps` calls of step() between barrier + device
+    sync on both sides.  The collector work (full collection + freeze, 40-60 ms of host time during which the device would
+    sit idle and come back at a lower clock: the first timed steps then read 12.3 / 11.0 / 10.8 ms instead of 10.4) is done IN
+    FRONT of the warm-up steps, so that only the barrier + sync separate the last warm-up step from the first timed one.
 
     No per-call instrumentation runs in here (the per-kernel roofline legs are separate passes AFTER it); what is recorded costs
     one pre-created event record and one perf_counter() per step:
@@ -486,9 +489,11 @@ def timed_region(step, steps, make_event=None, sync=None, barrier=None, alloc_st
     was_enabled = gc.isenabled()
     gc.disable()
     gc.callbacks.append(on_gc)
-    a0 = alloc_stats()
     loss = None
     try:
+        for _ in range(warmup):
+            step()
+        a0 = alloc_stats()
         if barrier:
             barrier()
         sync()
@@ -520,6 +525,7 @@ def timed_region(step, steps, make_event=None, sync=None, barrier=None, alloc_st
              # how far the host ran ahead of the device when the slowest step was enqueued (ms of queued work): > 0 means a
              # host pause of that size would have been hidden
              "host_lead_ms_at_max": sum(dev_ms[:imax + 1]) - (host[imax + 1] - host[0]) * 1e3,
+             "device_ms_all": [round(v, 3) for v in dev_ms], "host_ms_all": [round(v, 3) for v in host_ms],
              "gc_events": gc_events, "gc": "collect + freeze + disable around the timed region",
              "device_allocs_in_timed_region": a1.get("num_device_alloc", 0) - a0.get("num_device_alloc", 0),
              "alloc_retries_in_timed_region": a1.get("num_alloc_retries", 0) - a0.get("num_alloc_retries", 0),
@@ -638,9 +644,7 @@ def secondary_entry(dev, label, mode, dtype, batch, size, steps, warmup=2):
     job.make_optimizer()
     job.step()                                             # initialisation (buffers, descriptor tables)
     torch.cuda.synchronize()
-    for _ in range(warmup):
-        job.step()
-    elapsed, stats, _ = timed_region(job.step, steps)
+    elapsed, stats, _ = timed_region(job.step, steps, warmup=warmup)
     roof = igemm_leg(job.step, dtype, mode, nsteps=2)
     imgs = batch * steps
     gf = NOMINAL_GFLOP_IMG.get((mode, size))
@@ -728,12 +732,11 @@ def main():
     # one untimed step does that even when the caller asks for --warmup 0
     step()
     torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
     if args.per_layer:
+        for _ in range(args.warmup):
+            step()
         per_layer_table(step, args)
-    elapsed, step_stats, loss = timed_region(step, args.steps, barrier=dist.barrier if world > 1 else None)
-    local_elapsed = elapsed
+    elapsed, step_stats, loss = timed_region(step, args.steps, barrier=dist.barrier if world > 1 else None, warmup=args.warmup)
     ranks = None
     if world > 1:
         # MAX over ranks is the job's time; every rank's own time and median step go into the line as well

@@ -5,6 +5,7 @@ Tolerances: fp32 path -- exact-fp32 MFMA, only the summation order differs: rel-
 bf16 path -- inputs are pre-rounded to bf16 so both sides see identical operands; the error
 left is fp32-accumulate order + one bf16 rounding of the output (2^-9): rel-L2 <= 6e-3.
 """
+import ctypes
 import os
 
 import numpy as np

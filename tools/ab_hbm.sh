@@ -7,8 +7,8 @@ out=gpurun_out/${tag}_ab.txt
 for r in $(seq $rounds); do
   for arm in "$@"; do
     f=gpurun_out/${tag}_tmp.json
-    if [ "$arm" = "default" ]; then python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $f 2>/dev/null
-    else env $arm python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $f 2>/dev/null; fi
+    if [ "$arm" = "default" ]; then python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $f 2>/dev/null
+    else env $arm python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $f 2>/dev/null; fi
     python3 - "$f" "$arm" >> $out <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
