@@ -66,7 +66,7 @@ def igemm_flops(name, a, es=2):
     """(nominal dense FLOPs incl. padded taps, algorithmic bytes = input + weights + output read/written
     once) of one implicit-GEMM launch, from its C-ABI arguments."""
     if name in ("unetdc_conv3x3_fwd", "unetdc_conv3x3_fwd_bnin"):      # (bnin: input = the raw output of the stage in front)
-        n, h, w, cin, cout = a[10:15]
+        n, h, w, cin, cout = a[10:15] if name == "unetdc_conv3x3_fwd" else a[12:17]
         return 2.0 * n * h * w * cout * cin * 9, (n * h * w * (cin + cout) + 9 * cin * cout) * es
     if name == "unetdc_conv3x3_dgrad":
         n, h, w, cin, cout = a[5:10]
@@ -223,8 +223,10 @@ def executed_fraction(a, name, blocks16=False):
     d % 16 == 0): exactly the in-bounds tap-pixel pairs, 4 of 9 there.  1.0 for transposed convs and the halo-patch kernel."""
     if "convT" in name:
         return 1.0
-    if name in ("unetdc_conv3x3_fwd", "unetdc_conv3x3_fwd_bnin"):
+    if name == "unetdc_conv3x3_fwd":
         n, h, w, d = a[10], a[11], a[12], a[15]
+    elif name == "unetdc_conv3x3_fwd_bnin":
+        n, h, w, d = a[12], a[13], a[14], a[17]
     elif name == "unetdc_conv3x3_dgrad":
         n, h, w, d = a[5], a[6], a[7], a[10]
     elif name == "unetdc_conv3x3_dgrad_bnstats":

@@ -105,14 +105,17 @@ int unetdc_conv3x3_fwd(const void* x, int ldx, const void* w_fwd, const float* b
                        int cin, int cout, int dilation, int dtype, unetdc_stream_t s);
 /* "bnin" forms (round 3): the convolution / weight gradient are fed from the RAW conv output of the stage in front of them and
  * apply that stage's BatchNorm + ReLU -- relu(in_scale * x + in_shift), models/model_2.py:45-46, rounded through the storage
- * type like a stored activation -- once per staged tile in LDS: the stand-alone unetdc_bn_relu_apply pass of that stage and
- * its activation tensor disappear; outputs are bit-identical to the two-pass form.  bf16 only, shapes the persistent lattice
- * kernel (64-channel output form) and the tap-split ring weight gradient take: ask unetdc_conv3x3_bnin_supported first.
+ * type like a stored activation -- once per staged tile in LDS: the stand-alone unetdc_bn_relu_apply pass of that stage
+ * disappears; outputs are bit-identical to the two-pass form.  bf16 only, shapes the persistent lattice kernel takes.
+ * unetdc_conv3x3_bnin_supported() returns 0 (no), 1 (64-channel output blocks: forward + unetdc_conv3x3_wgrad_bnin, the activation
+ * tensor is never stored) or 2 (round 5, 128-channel output blocks: the forward ALSO stores the normalised activation into
+ * act_out [n*h*w][ldact] on request -- the bytes the stand-alone pass would have written, without its read of x and without its
+ * launch -- so that any weight-gradient kernel can follow; act_out must be NULL where the answer is 1).
  * fwd: statistics mode only (training); in_scale / in_shift [cin] are the producing stage's batch scale / shift. */
 int unetdc_conv3x3_bnin_supported(int n, int h, int w, int cin, int cout, int dilation, int dtype);
 int unetdc_conv3x3_fwd_bnin(const void* x_raw, int ldx, const float* in_scale, const float* in_shift, const void* w_fwd,
-                            const float* bias, void* y, int ldy, float* stats_part, int* stats_rows, int n, int h, int w,
-                            int cin, int cout, int dilation, int dtype, unetdc_stream_t s);
+                            const float* bias, void* y, int ldy, float* stats_part, int* stats_rows, void* act_out, int ldact,
+                            int n, int h, int w, int cin, int cout, int dilation, int dtype, unetdc_stream_t s);
 int unetdc_conv3x3_wgrad_bnin(const void* x_raw, int ldx, const float* in_scale, const float* in_shift, const void* dy,
                               int lddy, float* dw, void* workspace, int64_t workspace_bytes, int n, int h, int w, int cin,
                               int cout, int dilation, int dtype, unetdc_stream_t s);

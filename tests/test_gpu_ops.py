@@ -360,7 +360,10 @@ def test_bn_finalize_many_partial_rows(rows, c):
 
 
 @pytest.mark.parametrize("case", [(2, 256, 256, 64, 64, 1), (3, 512, 256, 64, 64, 1), (2, 64, 256, 64, 64, 2), (2, 96, 192, 64, 64, 1),
-                                  (2, 128, 128, 128, 64, 1)])
+                                  (2, 128, 128, 128, 64, 1),
+                                  # 128-channel n-blocks (round 5: the wide lattice kernel normalises on load too, constants through SGPRs)
+                                  (2, 128, 128, 128, 128, 1), (1, 128, 256, 256, 256, 1), (2, 64, 256, 128, 128, 2), (8, 64, 64, 512, 512, 1),
+                                  (3, 64, 192, 128, 256, 1)])
 def test_conv_and_wgrad_fed_from_raw_output_normalise_on_load(case):
     """unetdc_conv3x3_fwd_bnin / unetdc_conv3x3_wgrad_bnin (bf16): fed from the RAW output of the stage in front, they apply its
     BatchNorm + ReLU per staged tile in LDS.  Bit-identical to the two-pass form (unetdc_bn_relu_apply, then the plain
@@ -369,8 +372,8 @@ def test_conv_and_wgrad_fed_from_raw_output_normalise_on_load(case):
     n, h, w, cin, cout, d = case
     dtype = "bf16"
     lib = _lib.load()
-    assert lib.unetdc_conv3x3_bnin_supported(n, h, w, cin, cout, d, G.DT[dtype]) == 1
-    assert lib.unetdc_conv3x3_bnin_supported(n, h, w, cin, 128, d, G.DT[dtype]) == 0       # 128-channel n-blocks: not built
+    mode = lib.unetdc_conv3x3_bnin_supported(n, h, w, cin, cout, d, G.DT[dtype])
+    assert mode == (2 if cout % 128 == 0 else 1)        # 128-channel n-blocks: the forward can store the normalised activation
     g = gen(41)
     yraw = G.quant(torch.randn(n, cin, h, w, generator=g) * 1.5, dtype)
     sc, sh = (torch.rand(cin, generator=g) + 0.5).cuda(), (torch.randn(cin, generator=g) * 0.4 + 0.3).cuda()   # relu(shift) != 0
@@ -389,12 +392,21 @@ def test_conv_and_wgrad_fed_from_raw_output_normalise_on_load(case):
     o = G.empty_nhwc(n * h * w, cout, dtype)
     st = torch.full_like(st_ref, float("nan"))
     live = ctypes.c_int(-1)
+    act = G.empty_nhwc(n * h * w, cin, dtype, ld=cin + 64, off=32) if mode == 2 else None      # (strided view, NaN-filled)
     call("unetdc_conv3x3_fwd_bnin", yv.data_ptr(), yv.stride(0), sc.data_ptr(), sh.data_ptr(), wf.data_ptr(), b.data_ptr(),
-         o.data_ptr(), o.stride(0), st.data_ptr(), ctypes.byref(live), n, h, w, cin, cout, d, G.DT[dtype], G.stream())
+         o.data_ptr(), o.stride(0), st.data_ptr(), ctypes.byref(live), None if act is None else act.data_ptr(),
+         0 if act is None else act.stride(0), n, h, w, cin, cout, d, G.DT[dtype], G.stream())
     assert lib.unetdc_last_kernel().decode().endswith("bnin")
     assert live.value == live_ref >= 1
     assert torch.equal(o, o_ref)
     assert torch.equal(st[: rows * 2 * cout], st_ref[: rows * 2 * cout])
+    if act is not None:
+        assert torch.equal(act, av)                     # the stored activation == what the stand-alone pass writes, bit for bit
+    else:                                               # the 64-channel form has no write-back: asking for one is refused
+        with pytest.raises(_lib.UnetdcError, match="stores the activation"):
+            call("unetdc_conv3x3_fwd_bnin", yv.data_ptr(), yv.stride(0), sc.data_ptr(), sh.data_ptr(), wf.data_ptr(), b.data_ptr(),
+                 o.data_ptr(), o.stride(0), st.data_ptr(), ctypes.byref(live), av.data_ptr(), av.stride(0), n, h, w, cin, cout, d,
+                 G.DT[dtype], G.stream())
     # weight gradient
     dyv = G.to_nhwc(dy, dtype)
     dw_ref = G.conv3x3_wgrad(av, dyv, n, h, w, cin, cout, d, dtype)

@@ -16,8 +16,8 @@ done
 for r in 1 2; do
   for arm in A B; do
     f=gpurun_out/${tag}_${arm}_r${r}.json
-    if [ $arm = A ]; then UNETDC_LIB=$base python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline > $f 2>/dev/null
-    else python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline > $f 2>/dev/null; fi
+    if [ $arm = A ]; then UNETDC_LIB=$base python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-secondary > $f 2>/dev/null
+    else python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-secondary > $f 2>/dev/null; fi
     python3 - "$f" "$arm" >> $out <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

@@ -58,7 +58,7 @@ if op in ("fwd_bnin", "dgrad_bnstats", "wgrad_bnin"):
 def run():
     if op == "fwd_bnin":
         _lib.call("unetdc_conv3x3_fwd_bnin", x.data_ptr(), cin, sc_in.data_ptr(), sh_in.data_ptr(), wf.data_ptr(), bias.data_ptr(),
-                  y.data_ptr(), cout, stats.data_ptr(), None, n, h, w, cin, cout, d, DTI, G.stream())
+                  y.data_ptr(), cout, stats.data_ptr(), None, None, 0, n, h, w, cin, cout, d, DTI, G.stream())
     elif op == "dgrad_bnstats":
         _lib.call("unetdc_conv3x3_dgrad_bnstats", dy.data_ptr(), cout, wd.data_ptr(), dx.data_ptr(), cin, yprev.data_ptr(), cin,
                   sc_in.data_ptr(), sh_in.data_ptr(), mu_in.data_ptr(), rs_in.data_ptr(), stats.data_ptr(), stats.numel(),

@@ -31,7 +31,7 @@ SIGNATURES = {
     "unetdc_conv3x3_stats_rows": (I, [L, I]),
     "unetdc_conv3x3_fwd": (I, [P, I, P, P, P, P, P, I, P, P, I, I, I, I, I, I, I, P]),
     "unetdc_conv3x3_bnin_supported": (I, [I, I, I, I, I, I, I]),
-    "unetdc_conv3x3_fwd_bnin": (I, [P, I, P, P, P, P, P, I, P, P, I, I, I, I, I, I, I, P]),
+    "unetdc_conv3x3_fwd_bnin": (I, [P, I, P, P, P, P, P, I, P, P, P, I, I, I, I, I, I, I, I, P]),
     "unetdc_conv3x3_wgrad_bnin": (I, [P, I, P, P, P, I, P, P, L, I, I, I, I, I, I, I, P]),
     "unetdc_conv3x3_dgrad": (I, [P, I, P, P, I, I, I, I, I, I, I, I, P]),
     "unetdc_conv3x3_wgrad_workspace": (L, [I, I, I, I, I, I]),

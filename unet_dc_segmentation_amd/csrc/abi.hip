@@ -118,22 +118,27 @@ int unetdc_conv3x3_bnin_supported(int n, int h, int w, int cin, int cout, int di
   p.M = n * h * w; p.Ho = h; p.Wo = w; p.Hi = h; p.Wi = w; p.Cin = cin; p.Cout = cout; p.ldx = cin; p.ldo = cout;
   p.ntaps = 9; p.stride = 1; p.mode = MODE_STATS;
   taps3x3(dilation, p.offy, p.offx);
-  return (igemm_lattice_bnin_supported(p, dtype) && wgrad_bnin_supported(n, h, w, cout, cin, cout, cin, dilation, dtype)) ? 1 : 0;
+  if (!igemm_lattice_bnin_supported(p, dtype)) return 0;
+  if (igemm_lattice_bnin_writes_activation(p, dtype)) return 2;      // forward stores the activation: any weight-gradient kernel follows
+  return wgrad_bnin_supported(n, h, w, cout, cin, cout, cin, dilation, dtype) ? 1 : 0;
 }
 
 int unetdc_conv3x3_fwd_bnin(const void* x_raw, int ldx, const float* in_scale, const float* in_shift, const void* w_fwd,
-                            const float* bias, void* y, int ldy, float* stats_part, int* stats_rows, int n, int h, int w,
-                            int cin, int cout, int dilation, int dtype, unetdc_stream_t s) {
+                            const float* bias, void* y, int ldy, float* stats_part, int* stats_rows, void* act_out, int ldact,
+                            int n, int h, int w, int cin, int cout, int dilation, int dtype, unetdc_stream_t s) {
   GEOM_CHECK(n, h, w);
   UNETDC_REQUIRE(dilation >= 1 && ldx >= cin && ldy >= cout, "conv3x3_fwd_bnin: bad dilation/ld");
   UNETDC_REQUIRE(in_scale && in_shift && stats_part, "conv3x3_fwd_bnin: null pointer");
+  UNETDC_REQUIRE(act_out == nullptr || (ldact >= cin && ldact % 8 == 0), "conv3x3_fwd_bnin: bad activation ld");
   IgemmParams p{};
+  p.act_out = act_out; p.ld_act = ldact;
   p.x = x_raw; p.w = w_fwd; p.out = y; p.bias = bias; p.stats = stats_part; p.in_scale = in_scale; p.in_shift = in_shift;
   p.M = n * h * w; p.Ho = h; p.Wo = w; p.Hi = h; p.Wi = w; p.Cin = cin; p.Cout = cout; p.ldx = ldx; p.ldo = ldy;
   p.ntaps = 9; p.stride = 1; p.mode = MODE_STATS;
   taps3x3(dilation, p.offy, p.offx);
-  if (!igemm_lattice_bnin_supported(p, dtype)) {
-    set_error("conv3x3_fwd_bnin: shape not supported by the input-normalising kernel (ask unetdc_conv3x3_bnin_supported)");
+  if (!igemm_lattice_bnin_supported(p, dtype) || (act_out && !igemm_lattice_bnin_writes_activation(p, dtype))) {
+    set_error("conv3x3_fwd_bnin: shape not supported by the input-normalising kernel%s (ask unetdc_conv3x3_bnin_supported)",
+              act_out ? " that also stores the activation" : "");
     return UNETDC_EUNSUPPORTED;
   }
   const int rc = launch_igemm(p, dtype, (hipStream_t)s);

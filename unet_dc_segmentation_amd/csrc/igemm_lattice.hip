@@ -496,9 +496,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
 // chunk flip the parity per chunk (two fragment base sets, selected at compile time inside the unrolled taps).
 // Modes: STORE / STATS / AFFINE_RELU (the fused BatchNorm-backward epilogue keeps the 64-wide forms: its saved-output
 // prefetch does not fit the register budget next to 128 accumulators).
-template <int MODE>
+// INORM (round 5, statistics mode): the input is the RAW conv output of the stage in front; its BatchNorm + ReLU is applied once
+// per staged patch in LDS, as in igemm_lattice_kernel<..., INORM> -- but this form has no LDS left for the constants (80 KB
+// exactly, two workgroups per CU), so the chunk index is WAVE-UNIFORM here (wave w owns logical chunks 2w, 2w + 1 of every
+// pixel; a lane owns pixel lane + 64 i) and the 16 constants of a chunk come in through the scalar cache into SGPRs: no
+// vector-memory load joins the hand-counted DMA queue and no LDS is spent.  16 pixels of a wave-instruction cover the 8 XOR
+// keys x 2 bank halves exactly once: the 64 16-byte accesses of an instruction spread evenly over the banks.
+template <int MODE, bool INORM = false>
 __global__ __launch_bounds__(256, 2) void igemm_lattice_wide_kernel(const IgemmParams p, const LatticeParams q) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(!INORM || MODE == MODE_STATS, "input normalisation: the training forward");
   constexpr int WM = 4, WN = 1, MT = 4, NPB = 1, NG = 2;
   constexpr int NW = WM * WN, BN = WN * NG * 64;
   constexpr int BI = BN / 8 / NW;                 // weight DMA instructions per wave per tap
@@ -614,6 +621,63 @@ __global__ __launch_bounds__(256, 2) void igemm_lattice_wide_kernel(const IgemmP
 #pragma unroll
     for (int j = 0; j < BI; ++j)
       lds_dma16(wr, lds_base + OFF_W + stage * WST + (wave + NW * j) * 1024, valid ? bbase[j] : LOOB, soff);
+  };
+
+  // INORM: normalise the patch of (item, K chunk kc) in place (see the note above the kernel)
+  auto normalise_patch = [&](const Item& it, int kc) {
+#pragma unroll 1
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int lc = 2 * wave + h2;                 // wave-uniform logical chunk: channels kc * 64 + 8 lc .. + 7
+      float nsc[8], nsh[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { nsc[e] = p.in_scale[kc * 64 + lc * 8 + e]; nsh[e] = p.in_shift[kc * 64 + lc * 8 + e]; }
+#pragma unroll 1
+      for (int i = 0; i < (LPP + 63) / 64; ++i) {
+        int lane_here = lane;
+        asm volatile("" : "+v"(lane_here));         // opaque: nothing of this loop is hoisted across the tap loops (and then spilled)
+        const int pr = lane_here + 64 * i;
+        const int ppy = (pr * 1928) >> 16, ppx = pr - ppy * LPW;       // pr / 34
+        const int ly = it.ly0 + ppy - 1, lx = it.lx0 + ppx - 1;
+        if (pr < LPP && (unsigned)ly < (unsigned)q.Hs && (unsigned)lx < (unsigned)q.Ws) {
+          unsigned char* a = smem + pr * 128 + ((lc ^ ((ppx >> 1) & 7)) << 4);
+          float v[8];
+          Chunk<bf16_t>::unpack(ld16(a), v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], nsc[e], nsh[e]), 0.f);
+          st16(a, Chunk<bf16_t>::pack(v));
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    raw_barrier();
+  };
+  // ACTIVATION WRITE-BACK (at the END of a chunk, when every wave has issued its last MFMA on the patch and before the next
+  // chunk's patch overwrites it): the 8 x 32 interior of the normalised patch = this item's 256 pixels x 64 channels of the
+  // activation relu(scale * y + shift), exactly the bytes a stand-alone normalisation pass would have stored.  Written by the
+  // items of n-block 0 only (every n-block stages the same patch); 8 lanes = the 128-byte line of one pixel.  The LTH stores of a
+  // lane are older than the patch slices issued right behind them, so the wait of the next tap 0 ("the patch has landed") covers
+  // them: VMEM retires in order, no counted wait changes.
+  auto write_back = [&](const Item& it, int kc) {
+    if (p.act_out != nullptr && it.nblk == 0) {
+      const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(p.act_out, 0, 0xFFFFFFFFu, 0x00020000);
+      const unsigned ldab = (unsigned)(p.ld_act * 2);
+      // scalar part of the address: the item's first pixel and this chunk's channels; per-lane part: (row, column, 16-byte piece)
+      const unsigned sbase = (unsigned)__builtin_amdgcn_readfirstlane(
+          (int)((unsigned)((it.img * p.Ho + it.ly0 * d + it.phy) * p.Wo + it.lx0 * d + it.phx) * ldab + (unsigned)(kc * 128)));
+      int tid_here = tid;
+      asm volatile("" : "+v"(tid_here));            // opaque: nothing of this block is hoisted across the tap loops
+      const int c = tid_here & 7, colp = (tid_here >> 3) & 31, ppx = colp + 1;
+      unsigned la = (unsigned)((LPW + ppx) * 128 + ((c ^ ((ppx >> 1) & 7)) << 4));       // patch row 1 (+ LPW * 128 per row)
+      unsigned ga = (unsigned)(colp * d) * ldab + (unsigned)(c * 16);                      // lattice row 0 (+ d * Wo * ldab per row)
+      const unsigned grow = (unsigned)(d * p.Wo) * ldab;
+#pragma unroll 1
+      for (int row = 0; row < LTH; ++row) {
+        const u32x4 v = ld16(smem + la);
+        __builtin_amdgcn_raw_buffer_store_b128(v, ar, ga, sbase, 0);
+        la += LPW * 128;
+        ga += grow;
+      }
+    }
   };
 
   f32x4 acc[NG][MT][4];
@@ -815,6 +879,7 @@ __global__ __launch_bounds__(256, 2) void igemm_lattice_wide_kernel(const IgemmP
         // W(t) was issued one tap ago and nothing younger exists -- except, at t = 0 behind an item boundary, the epilogue stores
         if (t == 0 && boundary) wait_vmcnt<NST>(); else wait_vmcnt<0>();
         raw_barrier();
+        if (INORM && t == 0) normalise_patch(cur, kc);       // the patch of this chunk has landed (every wave's pieces)
         auto issue = [&]() {
           if (t < 8) issue_w((par + t + 1) & 1, t + 1, kc, cur.nblk, true);
           else issue_w((par + 9) & 1, 0, kc_n, nblk_n, have_n);
@@ -822,6 +887,11 @@ __global__ __launch_bounds__(256, 2) void igemm_lattice_wide_kernel(const IgemmP
         if (t & 1) compute_tap(t, bb1, issue); else compute_tap(t, bb0, issue);
       }
       raw_barrier();                              // every wave has issued the MFMAs of tap 8: the patch buffer is free
+      if (INORM && p.act_out != nullptr) {
+        write_back(cur, kc);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        raw_barrier();                            // every wave has READ its pieces: the next patch may overwrite them
+      }
 #pragma unroll
       for (int sl = 0; sl < PJ; ++sl) issue_slice(sl, 0, pb_n, pe_n);
       boundary = last_kc;
@@ -881,9 +951,15 @@ bool igemm_lattice_supported(const IgemmParams& p, int dtype) {
   return xbytes < (1L << 31) && wbytes < (1L << 31) && obytes < (1L << 32) && ybytes < (1L << 32);
 }
 
-// input normalisation on load: the 64-channel-output statistics forward of the 4-wave form
+// input normalisation on load: the statistics forward of the 4-wave forms (64-channel n-blocks: constants in LDS, Cin <= 256;
+// 128-channel n-blocks: constants through the scalar cache, any Cin)
 bool igemm_lattice_bnin_supported(const IgemmParams& p, int dtype) {
-  return igemm_lattice_supported(p, dtype) && p.mode == MODE_STATS && p.Cout % 128 != 0 && p.Cin <= 256;
+  return igemm_lattice_supported(p, dtype) && p.mode == MODE_STATS && (p.Cout % 128 == 0 || p.Cin <= 256);
+}
+
+// the wide form can also store the normalised activation (IgemmParams::act_out)
+bool igemm_lattice_bnin_writes_activation(const IgemmParams& p, int dtype) {
+  return igemm_lattice_bnin_supported(p, dtype) && p.Cout % 128 == 0 && (long)p.M * p.Cin * 2 < (1L << 32);
 }
 
 static long lattice_grid(long items, int wgs_per_cu) {
@@ -910,19 +986,19 @@ static int launch_lattice_cfg(IgemmParams& p, const LatticeParams& q, int wgs_pe
   return check_launch("igemm_lattice_kernel");
 }
 
-template <int MODE>
+template <int MODE, bool INORM = false>
 static int launch_lattice_wide_cfg(IgemmParams& p, const LatticeParams& q, hipStream_t stream) {
   constexpr int NW = 4, BN = 128, PJ = (LPI + NW - 1) / NW;
   constexpr int LDS = PJ * NW * 1024 + 2 * BN * 128 + NW * 2 * 128 * 4;       // 44 KB patch + 2 x 16 KB weights + 4 KB scratch = 80 KB
-  if (const int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&igemm_lattice_wide_kernel<MODE>), LDS, "igemm_lattice_wide_kernel")) return rc_;
+  if (const int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&igemm_lattice_wide_kernel<MODE, INORM>), LDS, "igemm_lattice_wide_kernel")) return rc_;
   const long grid = lattice_grid(q.items, 2);
   if (grid % q.nblocks != 0 || q.stat_rows != (int)(grid / q.nblocks)) {
     set_error("igemm_lattice_wide: grid %ld / nblocks %d / stat_rows %d inconsistent", grid, q.nblocks, q.stat_rows);
     return UNETDC_ELAUNCH;
   }
-  hipLaunchKernelGGL((igemm_lattice_wide_kernel<MODE>), dim3((unsigned)grid), dim3(NW * 64), LDS, stream, p, q);
+  hipLaunchKernelGGL((igemm_lattice_wide_kernel<MODE, INORM>), dim3((unsigned)grid), dim3(NW * 64), LDS, stream, p, q);
   char nm[96];
-  snprintf(nm, sizeof(nm), "igemm_lattice_wide_kernel<%d>", MODE);
+  snprintf(nm, sizeof(nm), "igemm_lattice_wide_kernel<%d>%s", MODE, INORM ? " bnin" : "");
   note_kernel(nm);
   return check_launch("igemm_lattice_wide_kernel");
 }
@@ -965,6 +1041,7 @@ int launch_igemm_lattice(IgemmParams& p, hipStream_t stream) {
   q.mg_d = magic(q.d); q.mg_tx = magic(q.tiles_x);
   p.nblocks = q.nblocks;
   if (ww) {
+    if (p.mode == MODE_STATS && p.in_scale) return launch_lattice_wide_cfg<MODE_STATS, true>(p, q, stream);
     if (p.mode == MODE_STATS) return launch_lattice_wide_cfg<MODE_STATS>(p, q, stream);
     if (p.mode == MODE_BNBWD) return launch_lattice_wide_cfg<MODE_BNBWD>(p, q, stream);
     return launch_lattice_wide_cfg<MODE_AFFINE_RELU>(p, q, stream);

@@ -30,6 +30,10 @@ struct IgemmParams {
   // in_shift) rounded through the storage type, is applied to every staged patch in LDS (igemm_lattice.hip, INORM)
   const float* in_scale;
   const float* in_shift;
+  // optional (wide INORM form): the normalised activation is ALSO written out, [M][ld_act], by the items of n-block 0 -- the
+  // weight gradient of the stage then reads a stored activation (plain kernel) without a stand-alone normalisation pass
+  void* act_out;
+  int ld_act;
   int offy[9];
   int offx[9];
 };
@@ -38,6 +42,7 @@ int igemm_mblocks(long M, int Cout);
 bool igemm_lattice_supported(const IgemmParams& p, int dtype);      // igemm_lattice.hip: persistent lattice-halo conv (bf16)
 int launch_igemm_lattice(IgemmParams& p, hipStream_t stream);
 bool igemm_lattice_bnin_supported(const IgemmParams& p, int dtype);  // x = raw conv output, BatchNorm + ReLU applied per staged patch
+bool igemm_lattice_bnin_writes_activation(const IgemmParams& p, int dtype);   // ... and that form can store the normalised activation
 bool igemm_dma16_supported(const IgemmParams& p, int dtype);
 int launch_igemm_dma16(IgemmParams& p, int cfg, hipStream_t stream);
 

@@ -251,12 +251,15 @@ class UNetEngine:
         # transposed convs: module, sizes, packed weights (shared), input view of the last forward
         self.up = {lvl: dict(self.weights.up[lvl]) for lvl in (4, 3, 2, 1)}
         # blocks whose second stage normalises the first stage's raw output on load
-        self.bnin_blocks = set()
+        # (value 1: the activation of stage 0 is never stored, the weight gradient normalises on load too; 2: the second stage's
+        #  forward stores it as a by-product and the plain weight-gradient kernel reads it -- unetdc_conv3x3_bnin_supported)
+        self.bnin_blocks = {}
         if FUSE_BNIN:
             for (name, idx), st in self.stages.items():
                 h, w = st.hw
-                if idx == 3 and lib.unetdc_conv3x3_bnin_supported(N, h, w, st.cin, st.cout, st.dil, self.dt):
-                    self.bnin_blocks.add(name)
+                mode = lib.unetdc_conv3x3_bnin_supported(N, h, w, st.cin, st.cout, st.dil, self.dt) if idx == 3 else 0
+                if mode:
+                    self.bnin_blocks[name] = mode
         # gradient-side buffers (allocated lazily on the first backward)
         self.grad_bufs = None
         # parameter order == model.parameters() order; flat gradient offsets
@@ -317,7 +320,7 @@ class UNetEngine:
             return _UNetFunction.apply(x, self, not model.training, *self.params)
         return self.forward(x, train=False)
 
-    def _stage_fwd(self, st, xin, dst, train, pooled=None, apply=True, frozen=False, bnin=None):
+    def _stage_fwd(self, st, xin, dst, train, pooled=None, apply=True, frozen=False, bnin=None, act_out=None):
         """conv -> BN -> ReLU.  xin: [npix, cin] view (or the NCHW image for the first stage);
         dst: [npix, cout] view receiving the activation; pooled: optional [npix/4, cout] view;
         apply=False (train mode only): stop after the batch statistics -- the consumer normalises on load."""
@@ -332,8 +335,10 @@ class UNetEngine:
             if bnin is not None:                   # xin = the RAW output of the stage in front, normalised per staged patch
                 call("unetdc_conv3x3_fwd_bnin", xin.data_ptr(), xin.stride(0), bnin[0].data_ptr(), bnin[1].data_ptr(),
                      st.w_fwd.data_ptr(), conv.bias.data_ptr(), y.data_ptr(), y.stride(0), st.stats.data_ptr(), _byref(self._rows),
-                     N, h, w, st.cin, st.cout, st.dil, self.dt, s)
+                     _ptr(act_out), act_out.stride(0) if act_out is not None else 0, N, h, w, st.cin, st.cout, st.dil, self.dt, s)
                 st.stat_rows = self._rows.value
+                if act_out is not None:            # the forward stored the normalised input: the weight gradient reads it
+                    st.x_in, st.bnin = act_out, None
             elif st.first:
                 call("unetdc_conv3x3_first_fwd", xin.data_ptr(), conv.weight.data_ptr(), conv.bias.data_ptr(),
                      None, None, y.data_ptr(), y.stride(0), st.stats.data_ptr(), N, h, w, st.cin, st.cout,
@@ -394,7 +399,8 @@ class UNetEngine:
             self._stage_fwd(s0, hin, self.a0[name], train, frozen=frozen, apply=not fuse)
             skip = self.cat[l + 1][:, c:]
             self._stage_fwd(self.stages[(name, 3)], s0.y if fuse else self.a0[name], skip, train, pooled=self.pool[l + 1],
-                            frozen=frozen, bnin=(s0.scale, s0.shift) if fuse else None)
+                            frozen=frozen, bnin=(s0.scale, s0.shift) if fuse else None,
+                            act_out=self.a0[name] if fuse and self.bnin_blocks[name] == 2 else None)
             hin = self.pool[l + 1]
         self._stage_fwd(self.stages[("bottleneck", 0)], hin, self.a0["bottleneck"], train, frozen=frozen)
         self._stage_fwd(self.stages[("bottleneck", 3)], self.a0["bottleneck"], self.a3["bottleneck"], train, frozen=frozen)
@@ -413,7 +419,8 @@ class UNetEngine:
             fuse = train and name in self.bnin_blocks
             self._stage_fwd(s0, self.cat[lvl], self.a0[name], train, frozen=frozen, apply=not fuse)
             self._stage_fwd(self.stages[(name, 3)], s0.y if fuse else self.a0[name], self.a3[name], train,
-                            apply=not head_norm, frozen=frozen, bnin=(s0.scale, s0.shift) if fuse else None)
+                            apply=not head_norm, frozen=frozen, bnin=(s0.scale, s0.shift) if fuse else None,
+                            act_out=self.a0[name] if fuse and self.bnin_blocks[name] == 2 else None)
             hin = self.a3[name]
         probs = torch.empty(N, self.oc, self.H, self.W, device=self.device, dtype=torch.float32)
         oc = self.model.out_conv
