@@ -94,7 +94,13 @@ def pmc_traffic(kernel):
     """Per-launch bytes past the L2 for `kernel` from the committed rocprofv3 PMC summary (separate FETCH_SIZE /
     WRITE_SIZE passes, gfx950 x2 correction on the read side; tools/pmc_traffic.sh), or None -- also None when the
     summary was measured on different kernel sources than the ones built here (source-hash stamp)."""
-    for tag in ("r04", "r03", "r02", "r01"):
+    # the C ABI reports "igemm_lattice_wide_kernel<1>" (+ " bnin" for the input-normalising instantiation); the symbol rocprofv3
+    # prints carries every template argument: igemm_lattice_wide_kernel<1, false> / <1, true>
+    base = kernel.split(" ")[0]
+    names = [kernel, base]
+    if base.startswith("igemm_lattice_wide_kernel<") and base.endswith(">"):
+        names.insert(0, base[:-1] + (", true>" if kernel.endswith(" bnin") else ", false>"))
+    for tag in ("r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
         try:
             doc = json.load(open(path))
@@ -108,8 +114,12 @@ def pmc_traffic(kernel):
         base, _, targs = kernel.partition("<")
         frag = base + "I" + "".join("DF16b" if a.strip() == "__bf16" else ("f" if a.strip() == "float" else f"Li{a.strip()}E")
                                     for a in targs.rstrip(">").split(",")) + "E" if targs else base
+        for cand in names:
+            for sym, v in table.items():
+                if cand in sym:
+                    return v["bytes_corrected"]
         for sym, v in table.items():
-            if frag in sym or kernel in sym:
+            if frag in sym:
                 return v["bytes_corrected"]
     return None
 

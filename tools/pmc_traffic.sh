@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 out=$PWD/gpurun_out/pmc_traffic_$tag
 mkdir -p $out
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --output-format csv --pmc $c -d $out/$c -o p -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > $out/$c.log 2>&1 \
+  rocprofv3 --output-format csv --pmc $c -d $out/$c -o p -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary > $out/$c.log 2>&1 \
     || { echo "pass failed: $c"; tail -5 $out/$c.log; exit 1; }
 done
 python3 tools/summarize_pmc.py $(find $out/FETCH_SIZE -name '*counter_collection.csv' | head -1) \

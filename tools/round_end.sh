@@ -5,7 +5,7 @@
 #                                                 line again so that roofline.traffic is filled in, the one-rank RCCL trace, the kernel
 #                                                 trace of the quantify flow
 #   tools/round_end.sh <round tag> 2              SQ counter passes of the main MFMA kernels (tools/sq_set.sh)
-r=${1:-r04}
+r=${1:-r05}
 part=${2:-1}
 export TMPDIR=/tmp
 set -e
