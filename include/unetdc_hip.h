@@ -128,44 +128,6 @@ int unetdc_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float
                          int64_t workspace_bytes, int n, int h, int w, int cin, int cout, int dilation, int dtype,
                          unetdc_stream_t s);
 
-/* ---- composed decoder up-path (round 5, bf16): conv3x3(W3[:, :C]) o convT2x2(WT) as ONE operator on the low-res tensor ----
- * Replaces upconvN + torch.cat + the first convolution of decN (models/model_2.py:67-69, 70-72, 73-75, 76-78) without ever
- * materialising `up`: for an output pixel of phase (py, px) the nine taps over `up` reach a 2 x 2 neighbourhood of the up-conv's
- * input h through composed weights W'[phase][tap][co][ci] (profiles/r05_upconv_composition_sizing.txt).
- * unetdc_upcomp_compose: from the packed images of decN.0 (w3_fwd [9][C][2C], w3_dgrad [9][2C][C]) and of upconvN (wt_dgrad
- *   [4][2C][C]) + the fp32 master of decN.0's weight and the two biases ->  wc_fwd [16][C][2C], wc_dgrad [16][2C][C] (the composed
- *   images), wskip_fwd / wskip_dgrad [9][C][C] (the skip half of decN.0 as dense images), btab [10][C] fp32 (row 0: the bias an
- *   interior pixel sees, rows 1..9: the ConvT bias through conv tap t).  Redo after every optimizer step.
- * unetdc_upcomp_fwd: y [n, 2 hlo, 2 wlo, C] = conv3x3(skip) + composed(h) + bias (three launches: skip half, border-bias pass,
- *   low-res half added onto it) and the BatchNorm partial statistics of y (same row layout as unetdc_conv3x3_fwd). */
-int unetdc_upcomp_supported(int n, int hlo, int wlo, int c, int dtype);
-int unetdc_upcomp_compose(const void* w3_fwd, const void* w3_dgrad, const void* wt_dgrad, const float* w3_master, const float* b3,
-                          const float* bt, void* wc_fwd, void* wc_dgrad, void* wskip_fwd, void* wskip_dgrad, float* btab, int c,
-                          int dtype, unetdc_stream_t s);
-int unetdc_upcomp_fwd(const void* skip, int ldskip, const void* wskip_fwd, const float* btab, const void* h, int ldh,
-                      const void* wc_fwd, void* y, int ldy, float* stats_part, int* stats_rows, int n, int hlo, int wlo, int c,
-                      int dtype, unetdc_stream_t s);
-/* Backward, input side.  The skip half of the concat gradient is an ordinary unetdc_conv3x3_dgrad with wskip_dgrad (cin = cout = C,
- * written into the [pixels, 2C] gradient buffer's second half).  unetdc_upcomp_dgrad_bnstats gives the gradient of the LOW-RES
- * tensor h [n, hlo, wlo, 2C] from dy [n, 2 hlo, 2 wlo, C] (= ConvT dgrad o conv dgrad of the up half, `dup` never stored) and,
- * like unetdc_convT2x2_dgrad_bnstats, the BatchNorm-backward partial sums of the stage that produced h. */
-int unetdc_upcomp_dgrad_bnstats(const void* dy, int lddy, const void* wc_dgrad, void* dh, int lddh, const void* y_prev,
-                                int ldy_prev, const float* scale, const float* shift, const float* mean, const float* rstd,
-                                float* parts, int64_t parts_floats, int* nparts, int n, int hlo, int wlo, int c, int dtype,
-                                unetdc_stream_t s);
-/* Backward, weight side: dw3 [C][2C][3][3] (decN.0.weight, both halves), dwt [2C][C][2][2] (upconvN.weight), dbt [C] (upconvN.bias),
- * all fp32 in PyTorch layout.  The sixteen blocks dW'[phase][tap] = sum_pixels h (x) dy come from one tap-fused kernel over the
- * low-res pixels; dW3[:, :C] and dWT follow by two small GEMMs with the packed images (wt_fwd [4C][2C], w3_dgrad [9][2C][C]); the skip
- * half is the ordinary 3 x 3 weight gradient; dbT = sum_t sum_co W3[co][c][t] * (sum of dy over the pixels whose tap t stays in the
- * image), from dy_total [C] (= sum of dy over all pixels: decN.0's conv-bias gradient) minus border rows / columns; the same sums
- * give the ConvT bias's term in dW3's up half (bt [C] = upconvN.bias).
- * workspace >= unetdc_upcomp_wgrad_workspace() bytes. */
-int64_t unetdc_upcomp_wgrad_workspace(int n, int hlo, int wlo, int c, int dtype);
-int unetdc_upcomp_wgrad(const void* h, int ldh, const void* skip, int ldskip, const void* dy, int lddy, const void* wt_fwd,
-                        const void* w3_dgrad, const float* w3_master, const float* bt, const float* dy_total, float* dw3, float* dwt,
-                        float* dbt, void* workspace, int64_t workspace_bytes, int n, int hlo, int wlo, int c, int dtype,
-                        unetdc_stream_t s);
-
 /* ---- first encoder convolution (small Cin, reads the NCHW fp32 image): model_2.py:10 (enc1.0) ---
  * w is the fp32 PyTorch-layout parameter itself.  Same scale/shift/stats semantics as above. */
 int unetdc_conv3x3_first_stats_rows(int64_t npixels, int cin, int cout);

@@ -36,12 +36,6 @@ SIGNATURES = {
     "unetdc_conv3x3_dgrad": (I, [P, I, P, P, I, I, I, I, I, I, I, I, P]),
     "unetdc_conv3x3_wgrad_workspace": (L, [I, I, I, I, I, I]),
     "unetdc_conv3x3_wgrad": (I, [P, I, P, I, P, P, L, I, I, I, I, I, I, I, P]),
-    "unetdc_upcomp_supported": (I, [I, I, I, I, I]),
-    "unetdc_upcomp_compose": (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, P]),
-    "unetdc_upcomp_fwd": (I, [P, I, P, P, P, I, P, P, I, P, P, I, I, I, I, I, P]),
-    "unetdc_upcomp_dgrad_bnstats": (I, [P, I, P, P, I, P, I, P, P, P, P, P, L, P, I, I, I, I, I, P]),
-    "unetdc_upcomp_wgrad_workspace": (L, [I, I, I, I, I]),
-    "unetdc_upcomp_wgrad": (I, [P, I, P, I, P, I, P, P, P, P, P, P, P, P, P, L, I, I, I, I, I, P]),
     "unetdc_conv3x3_first_stats_rows": (I, [L, I, I]),
     "unetdc_conv3x3_first_fwd": (I, [P, P, P, P, P, P, I, P, I, I, I, I, I, I, I, P]),
     "unetdc_conv3x3_first_wgrad_workspace": (L, [I, I, I, I, I]),

@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["abi.hip", "igemm_conv.hip", "igemm_dma.hip", "igemm_dma16.hip", "igemm_halo.hip", "igemm_lattice.hip", "upconv_compose.hip", "upconv_wgrad.hip", "wgrad.hip", "wgrad_dma.hip", "wgrad_fused.hip", "wgrad_rect.hip", "convt_wgrad.hip", "first_conv.hip", "first_conv_mfma.hip", "elementwise.hip", "loss.hip", "optim.hip", "ccl.hip", "preprocess.hip"]
+SOURCES = ["abi.hip", "igemm_conv.hip", "igemm_dma.hip", "igemm_dma16.hip", "igemm_halo.hip", "igemm_lattice.hip", "wgrad.hip", "wgrad_dma.hip", "wgrad_fused.hip", "wgrad_rect.hip", "convt_wgrad.hip", "first_conv.hip", "first_conv_mfma.hip", "elementwise.hip", "loss.hip", "optim.hip", "ccl.hip", "preprocess.hip"]
 HEADERS = ["common.h", "kernels.h", "lds_dma.h", "wgrad_frag.h", "igemm_epilogue.h", "igemm_epilogue16.h", os.path.join("..", "..", "include", "unetdc_hip.h")]
 OUT = os.path.join(HERE, "libunetdc_hip.so")
 

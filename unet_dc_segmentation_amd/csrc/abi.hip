@@ -277,134 +277,6 @@ int unetdc_conv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, float
   return launch_wgrad(p, dw, workspace, (long)workspace_bytes, dtype, (hipStream_t)s);
 }
 
-// ---- composed decoder up-path (bf16): conv3x3(W3[:, :C]) o convT2x2(WT) on the low-res tensor ----
-int unetdc_upcomp_supported(int n, int hlo, int wlo, int c, int dtype) {
-  if (dtype != UNETDC_BF16 || n <= 0 || hlo <= 0 || wlo <= 0 || c < 64) return 0;
-  if (!igemm_lattice_up_supported(n, hlo, wlo, 2 * c, c, 2 * c, 2 * c)) return 0;
-  IgemmParams p{};                                           // the skip half: an ordinary 3 x 3 convolution of the 2x finer map
-  p.M = n * 4 * hlo * wlo; p.Ho = 2 * hlo; p.Wo = 2 * wlo; p.Hi = p.Ho; p.Wi = p.Wo; p.Cin = c; p.Cout = c; p.ldx = 2 * c; p.ldo = c;
-  p.ntaps = 9; p.stride = 1; p.mode = MODE_STORE;
-  taps3x3(1, p.offy, p.offx);
-  return igemm_lattice_supported(p, dtype) ? 1 : 0;
-}
-
-int unetdc_upcomp_compose(const void* w3_fwd, const void* w3_dgrad, const void* wt_dgrad, const float* w3_master, const float* b3,
-                          const float* bt, void* wc_fwd, void* wc_dgrad, void* wskip_fwd, void* wskip_dgrad, float* btab, int c,
-                          int dtype, unetdc_stream_t s) {
-  UNETDC_REQUIRE(dtype == UNETDC_BF16, "upcomp_compose: bf16 only");
-  return launch_upc_compose(w3_fwd, w3_dgrad, wt_dgrad, w3_master, b3, bt, wc_fwd, wc_dgrad, wskip_fwd, wskip_dgrad, btab, c,
-                            (hipStream_t)s);
-}
-
-int unetdc_upcomp_fwd(const void* skip, int ldskip, const void* wskip_fwd, const float* btab, const void* h, int ldh,
-                      const void* wc_fwd, void* y, int ldy, float* stats_part, int* stats_rows, int n, int hlo, int wlo, int c,
-                      int dtype, unetdc_stream_t s) {
-  GEOM_CHECK(n, hlo, wlo);
-  UNETDC_REQUIRE(skip && wskip_fwd && btab && h && wc_fwd && y && stats_part, "upcomp_fwd: null pointer");
-  UNETDC_REQUIRE(ldskip >= c && ldh >= 2 * c && ldy >= c, "upcomp_fwd: ld smaller than channel count");
-  if (!unetdc_upcomp_supported(n, hlo, wlo, c, dtype)) {
-    set_error("upcomp_fwd: shape not supported (ask unetdc_upcomp_supported)");
-    return UNETDC_EUNSUPPORTED;
-  }
-  // 1. skip half: y = conv3x3(skip) + (b3 + the ConvT bias through all nine taps)
-  IgemmParams p{};
-  p.x = skip; p.w = wskip_fwd; p.out = y; p.bias = btab;
-  p.M = n * 4 * hlo * wlo; p.Ho = 2 * hlo; p.Wo = 2 * wlo; p.Hi = p.Ho; p.Wi = p.Wo; p.Cin = c; p.Cout = c; p.ldx = ldskip; p.ldo = ldy;
-  p.ntaps = 9; p.stride = 1; p.mode = MODE_STORE;
-  taps3x3(1, p.offy, p.offx);
-  int rc = launch_igemm(p, dtype, (hipStream_t)s);
-  if (rc != UNETDC_OK) return rc;
-  // 2. border pixels: the taps that leave the image carry no ConvT bias
-  rc = launch_upc_border_bias(y, ldy, btab, n, 2 * hlo, 2 * wlo, c, (hipStream_t)s);
-  if (rc != UNETDC_OK) return rc;
-  // 3. low-res half, added onto it, + the BatchNorm statistics of the sum
-  IgemmParams u{};
-  u.x = h; u.w = wc_fwd; u.out = y; u.bn_y = y; u.bn_ldy = ldy; u.stats = stats_part;
-  u.M = p.M; u.Ho = p.Ho; u.Wo = p.Wo; u.Hi = hlo; u.Wi = wlo; u.Cin = 2 * c; u.Cout = c; u.ldx = ldh; u.ldo = ldy;
-  u.ntaps = 4; u.stride = 1;
-  rc = launch_lattice_up_fwd(u, hlo, wlo, (hipStream_t)s);
-  if (rc == UNETDC_OK && stats_rows) *stats_rows = u.mblocks;
-  return rc;
-}
-
-// gradient of the low-res tensor through the composed operator (dcat's up half and the ConvT input gradient in one step) + the
-// BatchNorm-backward partial sums of the stage that produced the low-res tensor; dy = gradient of decN.0's conv output
-int unetdc_upcomp_dgrad_bnstats(const void* dy, int lddy, const void* wc_dgrad, void* dh, int lddh, const void* y_prev,
-                                int ldy_prev, const float* scale, const float* shift, const float* mean, const float* rstd,
-                                float* parts, int64_t parts_floats, int* nparts, int n, int hlo, int wlo, int c, int dtype,
-                                unetdc_stream_t s) {
-  GEOM_CHECK(n, hlo, wlo);
-  UNETDC_REQUIRE(dy && wc_dgrad && dh && y_prev && scale && shift && mean && rstd && parts && nparts, "upcomp_dgrad: null pointer");
-  UNETDC_REQUIRE(lddy >= c && lddh >= 2 * c && ldy_prev >= 2 * c, "upcomp_dgrad: ld smaller than channel count");
-  if (!unetdc_upcomp_supported(n, hlo, wlo, c, dtype)) {
-    set_error("upcomp_dgrad: shape not supported (ask unetdc_upcomp_supported)");
-    return UNETDC_EUNSUPPORTED;
-  }
-  IgemmParams p{};
-  p.x = dy; p.w = wc_dgrad; p.out = dh;
-  p.M = n * hlo * wlo; p.Ho = hlo; p.Wo = wlo; p.Hi = 2 * hlo; p.Wi = 2 * wlo; p.Cin = c; p.Cout = 2 * c; p.ldx = lddy; p.ldo = lddh;
-  p.ntaps = 4; p.stride = 1;
-  const int rows = igemm_mblocks((long)p.M, p.Cout);
-  UNETDC_REQUIRE((int64_t)(rows + 64) * 3 * p.Cout <= parts_floats, "upcomp_dgrad: partial buffer too small");
-  p.stats = parts; p.bn_y = y_prev; p.bn_ldy = ldy_prev; p.scale = scale; p.shift = shift; p.bn_mean = mean; p.bn_rstd = rstd;
-  const int rc = launch_lattice_up_dgrad(p, hlo, wlo, (hipStream_t)s);
-  if (rc == UNETDC_OK) *nparts = p.mblocks;
-  return rc;
-}
-
-// weight-side backward of the composed up-path: dW3 (both halves), dWT and dbT
-//   workspace layout: [slabs of the two pixel-side kernels (shared)] [dwb, dwbt: 2 x 16 C 2C bf16] [skip half dW: C C 9 fp32] [border sums: 4 n C fp32]
-static int64_t upcomp_wgrad_slab_bytes(int n, int hlo, int wlo, int c, int dtype) {
-  const int64_t a = upc_wgrad_workspace_bytes(n, hlo, wlo, 2 * c, c);
-  const int64_t b = unetdc_conv3x3_wgrad_workspace(n, 2 * hlo, 2 * wlo, c, c, dtype);
-  return ((a > b ? a : b) + 255) & ~(int64_t)255;
-}
-int64_t unetdc_upcomp_wgrad_workspace(int n, int hlo, int wlo, int c, int dtype) {
-  return upcomp_wgrad_slab_bytes(n, hlo, wlo, c, dtype) + 2L * 16 * c * 2 * c * 2 + (int64_t)c * c * 9 * 4 + (4L * n + 9) * c * 4 + 1024;
-}
-
-int unetdc_upcomp_wgrad(const void* h, int ldh, const void* skip, int ldskip, const void* dy, int lddy, const void* wt_fwd,
-                        const void* w3_dgrad, const float* w3_master, const float* bt, const float* dy_total, float* dw3, float* dwt,
-                        float* dbt, void* workspace, int64_t workspace_bytes, int n, int hlo, int wlo, int c, int dtype,
-                        unetdc_stream_t s) {
-  GEOM_CHECK(n, hlo, wlo);
-  UNETDC_REQUIRE(h && skip && dy && wt_fwd && w3_dgrad && w3_master && bt && dy_total && dw3 && dwt && dbt && workspace,
-                 "upcomp_wgrad: null pointer");
-  UNETDC_REQUIRE(ldh >= 2 * c && ldskip >= c && lddy >= c, "upcomp_wgrad: ld smaller than channel count");
-  if (!unetdc_upcomp_supported(n, hlo, wlo, c, dtype) || !upc_wgrad_supported(n, hlo, wlo, 2 * c, c, ldh, lddy)) {
-    set_error("upcomp_wgrad: shape not supported (ask unetdc_upcomp_supported)");
-    return UNETDC_EUNSUPPORTED;
-  }
-  if (workspace_bytes < unetdc_upcomp_wgrad_workspace(n, hlo, wlo, c, dtype)) {
-    set_error("upcomp_wgrad: workspace too small (%ld bytes)", (long)workspace_bytes);
-    return UNETDC_EWORKSPACE;
-  }
-  const int64_t slab = upcomp_wgrad_slab_bytes(n, hlo, wlo, c, dtype);
-  unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
-  void* dwb = ws + slab;
-  void* dwbt = ws + slab + 16L * c * 2 * c * 2;
-  float* tmp = reinterpret_cast<float*>(ws + slab + 2L * 16 * c * 2 * c * 2);
-  float* bsum = tmp + (long)c * c * 9;
-  hipStream_t st = (hipStream_t)s;
-  // 1. the sixteen blocks of dW' (low-res tensor x phase sub-lattices of dy), then dW3[:, :C] and dWT out of them
-  int rc = launch_upc_wgrad(h, ldh, dy, lddy, dwb, dwbt, ws, (long)slab, n, hlo, wlo, 2 * c, c, st);
-  if (rc != UNETDC_OK) return rc;
-  rc = launch_upc_decompose(dwb, dwbt, wt_fwd, w3_dgrad, dw3, dwt, c, st);
-  if (rc != UNETDC_OK) return rc;
-  // 2. skip half: the ordinary weight gradient (dense [C][C][3][3]) moved into columns [C, 2C) of dW3
-  WgradParams p{};
-  p.a = dy; p.b = skip; p.N = n; p.H = 2 * hlo; p.W = 2 * wlo; p.Hb = p.H; p.Wb = p.W; p.CI = c; p.CJ = c;
-  p.lda = lddy; p.ldb = ldskip; p.ntaps = 9; p.stride = 1;
-  taps3x3(1, p.offy, p.offx);
-  rc = launch_wgrad(p, tmp, ws, (long)slab, dtype, st);
-  if (rc != UNETDC_OK) return rc;
-  rc = launch_upc_skip_scatter(tmp, dw3, c, st);
-  if (rc != UNETDC_OK) return rc;
-  // 3. the ConvT bias: its gradient, and its term in dW3's up half, from the border sums of dy (dy_total = sum of dy over all
-  //    pixels = decN.0's conv-bias gradient)
-  return launch_upc_dbt(w3_master, bt, dy_total, dy, lddy, bsum, dw3, dbt, n, 2 * hlo, 2 * wlo, c, st);
-}
-
 int unetdc_conv3x3_first_stats_rows(int64_t npixels, int cin, int cout) {
   return first_conv_mblocks((long)npixels, cin, cout);
 }

@@ -63,18 +63,18 @@ __device__ __forceinline__ void epilogue16c(const IgemmParams& p, f32x4 (&acc)[T
                                             unsigned yrow_bytes, const Epi16Consts& kc, float (&s)[4], float (&q)[4],
                                             const u32x2 (*ypre)[4] = nullptr) {
   const __amdgpu_buffer_rsrc_t orr = whole_buffer(p.out);
-  const __amdgpu_buffer_rsrc_t yrr = whole_buffer((MODE == MODE_BNBWD || MODE == MODE_STATS_ADD) ? p.bn_y : p.out);
+  const __amdgpu_buffer_rsrc_t yrr = whole_buffer(MODE == MODE_BNBWD ? p.bn_y : p.out);
   const float (&k0)[4] = kc.k0, (&k1)[4] = kc.k1, (&mu)[4] = kc.mu, (&rs)[4] = kc.rs;
   constexpr int GRP = TMT < 4 ? TMT : 4;                  // tiles whose saved-output loads are in flight together
 #pragma unroll
   for (int i0 = 0; i0 < TMT; i0 += GRP) {
     u32x2 yraw[GRP][4];
-    if ((MODE == MODE_BNBWD || MODE == MODE_STATS_ADD) && YPRE) {
+    if (MODE == MODE_BNBWD && YPRE) {
 #pragma unroll
       for (int ii = 0; ii < GRP; ++ii)
 #pragma unroll
         for (int v = 0; v < 4; ++v) yraw[ii][v] = ypre[i0 + ii][v];
-    } else if (MODE == MODE_BNBWD || MODE == MODE_STATS_ADD) {
+    } else if (MODE == MODE_BNBWD) {
 #pragma unroll
       for (int ii = 0; ii < GRP; ++ii)
 #pragma unroll
@@ -94,18 +94,13 @@ __device__ __forceinline__ void epilogue16c(const IgemmParams& p, f32x4 (&acc)[T
         if (MODE == MODE_AFFINE_RELU) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) x[k] = fmaxf(fmaf(x[k], k0[k], k1[k]), 0.f);
-        } else if (MODE == MODE_STATS_ADD) {               // + the partial sums of the other launch, as stored (bf16)
-          float a4[4];
-          unpack4_bf16(yraw[ii][v], a4);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) x[k] += k1[k] + a4[k];
         } else if (MODE != MODE_BNBWD) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) x[k] += k1[k];
         }
         const u32x2 pk = pack4_bf16(x[0], x[1], x[2], x[3]);
         __builtin_amdgcn_raw_buffer_store_b64(pk, orr, voff[i], (unsigned)v * row_bytes, 0);
-        if (MODE == MODE_STATS || MODE == MODE_STATS_ADD) {
+        if (MODE == MODE_STATS) {
           float t[4];
           unpack4_bf16(pk, t);
 #pragma unroll

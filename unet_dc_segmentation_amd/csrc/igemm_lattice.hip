@@ -55,7 +55,6 @@ struct LatticeParams {
   unsigned mg_nblocks, mg_tpi, mg_tpp, mg_d, mg_tx;   // ceil(2^32 / divisor) for the item decode (exact for n * divisor < 2^32)
   int stat_rows;              // statistics rows with data = gridDim.x / nblocks (one per workgroup and n-block), 0: per-tile rows
   int mtiles;                 // N * tiles_per_img = M / 256: rows [stat_rows, mtiles) are written as zeros
-  int kshift;                 // CMP == 2: log2(Cin / 64): K chunk kc = (phase << kshift) | channel chunk
 };
 // s_setprio 1 through the tap loops, 0 in the epilogues (settled in round 3, profiles/r03_setprio_ab.txt).
 // The round-2/3 timing probes that removed barriers / waits / DMAs (UNETDC_LAT_DBG: invalid results) are gone from the library;
@@ -74,30 +73,17 @@ template <int PJ, int SPT> __device__ constexpr int lat_nsl(int t) {
 // A thread owns one logical 16-byte chunk (8 channels: its 16 constants live in registers) of every 32nd patch pixel; padding
 // pixels (outside the sub-lattice) were zero-filled by the DMA and stay zero, which is what zero padding of the ACTIVATION means.
 // The result is rounded through bf16 like a stored activation: outputs are bit-identical to the two-pass form.
-// CMP (round 5, composed up-path: conv3x3(W3[:, :C]) o convT2x2(WT) as ONE operator on the low-res tensor, see
-// profiles/r05_upconv_composition_sizing.txt).  Both forms run FOUR taps per K chunk -- the 2 x 2 low-res neighbourhood --
-// at patch positions (by + ty, bx + tx), (ty, tx) in {0, 1}^2, with a phase-specific weight image [16][Cout][Cin] (index
-// phase * 4 + 2 ty + tx) and a 4-stage weight ring (stage = tap):
-//   CMP == 1  forward: the input is the DENSE low-res tensor (gather stride 1, no phase), an item = one 8 x 32 tile of ONE
-//             output phase of the 2x finer output (stored with stride 2, as the d = 2 layers store); (by, bx) = the item's phase;
-//   CMP == 2  input gradient: the phase runs in the K loop (chunk kc = (phase << kshift) | channel chunk; the patch of a chunk
-//             is gathered from that phase's sub-lattice of the 2x finer gradient, stride 2, as the d = 2 layers gather), the
-//             output is the dense low-res tensor; (by, bx) = (1 - phase_y, 1 - phase_x).
-template <int WM, int WN, int MT, int NPB, int MODE, bool INORM = false, int CMP = 0>
+template <int WM, int WN, int MT, int NPB, int MODE, bool INORM = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const IgemmParams p, const LatticeParams q) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(!INORM || (NPB == 1 && WM * WN == 4), "input normalisation: the 4-wave single-buffer form");
-  static_assert(CMP == 0 || (NPB == 1 && WM * WN == 4 && !INORM && (MODE == MODE_BNBWD || MODE == MODE_STATS_ADD)),
-                "composed up-path: the 4-wave single-buffer form with a prefetched epilogue operand");
   constexpr int NW = WM * WN, BN = WN * 64;
-  constexpr int NT = CMP ? 4 : 9;                 // taps per K chunk
-  constexpr int NWS = CMP ? 4 : 3;                // weight ring stages (NT % NWS == 0: the stage of a tap is the same in every chunk)
   constexpr int BI = BN / 8 / NW;                 // weight DMA instructions per wave per tap
   constexpr int PJ = (LPI + NW - 1) / NW;         // patch DMA instructions per wave per chunk (uniform: padded)
   constexpr int SPT = (NW == 4) ? 3 : 2;          // patch slices per tap while prefetching
   constexpr int PBUF = PJ * NW * 1024;            // bytes per patch buffer
   constexpr int WST = BN * 128;                   // bytes per weight stage
-  constexpr int OFF_W = NPB * PBUF, OFF_RED = OFF_W + NWS * WST;
+  constexpr int OFF_W = NPB * PBUF, OFF_RED = OFF_W + 3 * WST;
   constexpr int NST = MT * 4;                     // epilogue stores per wave and tile
   static_assert(WM * MT == 16 && (MT % 2) == 0, "a workgroup owns 16 M-tiles = 8 rows x 32 pixels");
   static_assert(BN % (8 * NW) == 0, "weight rows / wave mismatch");
@@ -108,15 +94,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
   const int wm = wave / WN, wn = wave % WN;
   const unsigned lds_base = lds_addr_of(smem);
   const int G = gridDim.x;
-  const int d = (CMP == 1) ? 1 : q.d;             // gather stride of the INPUT (CMP == 1: the dense low-res tensor)
-  const int dout = (CMP == 2) ? 1 : q.d;          // stride of the OUTPUT pixels (CMP == 2: the dense low-res tensor)
+  const int d = q.d;
 
   // The patch origin (-1, -1) of a border tile lies in front of the tensor; the scalar part of a DMA address (soffset)
   // cannot be negative, so the descriptor starts SH bytes early (those bytes are never touched: halo lanes outside the
   // image carry an out-of-range voffset and read zeros).
   const unsigned SH = (unsigned)((d * p.Wi + d) * p.ldx * 2);
   const unsigned xbytes = (unsigned)((long)(p.M / (p.Ho * p.Wo)) * p.Hi * p.Wi * p.ldx * 2) + SH;
-  const unsigned wbytes = (unsigned)((long)(CMP ? 16 : 9) * p.Cout * p.Cin * 2);
+  const unsigned wbytes = (unsigned)((long)9 * p.Cout * p.Cin * 2);
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.x)) - SH, 0, xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, wbytes, 0x00020000);
@@ -182,8 +167,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
     const int tpp = q.tiles_x * q.tiles_y;        // tiles per phase
     const int ph = (int)udiv((unsigned)r, q.mg_tpp, (unsigned)tpp);
     r -= ph * tpp;
-    it.phy = (int)udiv((unsigned)ph, q.mg_d, (unsigned)q.d);       // (q.d: the lattice stride; `d` is the INPUT stride, 1 for CMP == 1)
-    it.phx = ph - it.phy * q.d;
+    it.phy = (int)udiv((unsigned)ph, q.mg_d, (unsigned)d);
+    it.phx = ph - it.phy * d;
     const int ty = (int)udiv((unsigned)r, q.mg_tx, (unsigned)q.tiles_x);
     it.ly0 = ty * LTH;
     it.lx0 = (r - ty * q.tiles_x) * LTW;
@@ -195,12 +180,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
   // ---- DMA issue -----------------------------------------------------------------------------------------------------
   // scalar description of the patch of (item, K chunk): byte offset of its origin (+SH) and which borders it touches
   auto patch_base = [&](const Item& it, int kc) {
-    if (CMP == 1)                                 // dense low-res input: no phase on the input side (the item's phase selects taps / weights)
-      return (unsigned)((((it.img * p.Hi + (it.ly0 - 1)) * p.Wi + (it.lx0 - 1)) * p.ldx) * 2 + kc * 128) + SH;
-    if (CMP == 2) {                               // the chunk's phase selects the sub-lattice of the input
-      const int ph = kc >> q.kshift, kcc = kc - (ph << q.kshift);
-      return (unsigned)((((it.img * p.Hi + (it.ly0 - 1) * d + (ph >> 1)) * p.Wi + (it.lx0 - 1) * d + (ph & 1)) * p.ldx) * 2 + kcc * 128) + SH;
-    }
     return (unsigned)((((it.img * p.Hi + (it.ly0 - 1) * d + it.phy) * p.Wi + (it.lx0 - 1) * d + it.phx) * p.ldx) * 2 + kc * 128) + SH;
   };
   auto patch_edges = [&](const Item& it, bool valid) {
@@ -217,11 +196,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
                         (pr >= LPP ? 16u : 0u) | 32u) & edges;
     lds_dma16(xr, lds_base + buf * PBUF + (wave + NW * sl) * 1024, f ? LOOB : rel, pbase);
   };
-  // (CMP: `ph` = phase of the item (1) / of the chunk (2): the weight image is [phase * 4 + tap][Cout][Cin]; CMP == 2: kc carries the phase)
-  auto issue_w = [&](int stage, int tap, int kc, int nblk, bool valid, int ph = 0) {
-    const int wt = CMP == 1 ? ph * 4 + tap : (CMP == 2 ? (kc >> q.kshift) * 4 + tap : tap);
-    const int kcc = CMP == 2 ? kc & ((1 << q.kshift) - 1) : kc;
-    const unsigned soff = (unsigned)(((wt * p.Cout + nblk * BN) * p.Cin + kcc * 64) * 2);
+  auto issue_w = [&](int stage, int tap, int kc, int nblk, bool valid) {
+    const unsigned soff = (unsigned)(((tap * p.Cout + nblk * BN) * p.Cin + kc * 64) * 2);
 #pragma unroll
     for (int j = 0; j < BI; ++j)
       lds_dma16(wr, lds_base + OFF_W + stage * WST + (wave + NW * j) * 1024, valid ? bbase[j] : LOOB, soff);
@@ -273,8 +249,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
   // one tap: fragments of both 32-channel halves, MT*4*2 MFMAs
   // (the 4-wave BatchNorm-backward variant also carries the prefetched saved outputs: there the two halves take turns
   //  in ONE fragment register set, everywhere else both halves are read up front)
-  constexpr bool SPLIT_FRAGS = ((MODE == MODE_BNBWD || MODE == MODE_STATS_ADD) && NW == 4);
-  static_assert(CMP == 0 || SPLIT_FRAGS, "composed up-path: the split-fragment tap body");
+  constexpr bool SPLIT_FRAGS = (MODE == MODE_BNBWD && NW == 4);
   u32x4 fa_live[2][MT];
   // `issue`: this tap's vector-memory statements (weights two taps ahead, patch slices, saved-output prefetch), placed BEHIND
   // the tap's first fragment reads so that those are in flight while the wave gets its DMA instructions accepted
@@ -285,7 +260,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
         u32x4 fa[MT], fb[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[j] = ld16(smem + boff[g] + stage * WST + j * 16 * 128);
-        // (CMP: `ab` is the chunk's [tx][g] base set -- phase column shift and phase row already inside -- and ky, kx = ty, tx)
 #pragma unroll
         for (int i = 0; i < MT; ++i) fa[i] = ld16(smem + ab[kx][g] + ((i >> 1) + ky) * (LPW * 128) + (i & 1) * (16 * 128));
         if (g == 0) issue();
@@ -335,15 +309,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
   // MODE_BNBWD: the consumer stage's saved conv outputs of this item, fetched YT taps before the item's last MFMA.  They
   // sit in the VM queue between the weight DMAs: the counted waits of the two taps after the fetch leave them in flight
   // (+NY), from the third tap on an in-order wait would require them -- so the fetch goes at tap 6 of the last chunk.
-  // (MODE_STATS_ADD: the same machinery fetches the addend -- the partial sums another launch left in the output tensor)
-  constexpr int YT = NT - 3, NY = (MODE == MODE_BNBWD || MODE == MODE_STATS_ADD) ? MT * 4 : 0;
+  constexpr int YT = 6, NY = (MODE == MODE_BNBWD) ? MT * 4 : 0;
   u32x2 ypre[MT][4];
   auto item_offsets = [&](const Item& it, unsigned (&voff)[MT], unsigned (&yoff)[MT]) {
     const int col = it.nblk * BN + wn * 64 + 4 * c16;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const int gm = wm * MT + i;                                            // M tile of the workgroup: row gm >> 1, half gm & 1
-      const int Y = (it.ly0 + (gm >> 1)) * dout + it.phy, X = (it.lx0 + 16 * (gm & 1) + xb) * dout + it.phx;
+      const int Y = (it.ly0 + (gm >> 1)) * d + it.phy, X = (it.lx0 + 16 * (gm & 1) + xb) * d + it.phx;
       const unsigned pix = (unsigned)((it.img * p.Ho + Y) * p.Wo + X);
       voff[i] = pix * ldob + (unsigned)(col * 2);
       yoff[i] = pix * ldyb + (unsigned)(col * 2);
@@ -352,7 +325,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
   Epi16Consts ec;
   auto load_consts = [&](int nblk) {
     ec = epi16_consts<MODE>(p, nblk * BN + wn * 64 + 4 * c16);
-    if (MODE == MODE_STORE || MODE == MODE_STATS || MODE == MODE_STATS_ADD) {        // "+ bias" modes: fold it into the accumulator init
+    if (MODE == MODE_STORE || MODE == MODE_STATS) {        // "+ bias" modes: fold it into the accumulator init
 #pragma unroll
       for (int k = 0; k < 4; ++k) { binit[k] = ec.k1[k]; ec.k1[k] = 0.f; }
     }
@@ -366,9 +339,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
 #pragma unroll
     for (int i = 0; i < MT; ++i) tile_ok[i] = true;
     float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
-    const unsigned rbytes = 2u * (unsigned)dout * ldob, yrbytes = 2u * (unsigned)dout * ldyb;   // accumulator rows are 2 lattice pixels apart
+    const unsigned rbytes = 2u * (unsigned)d * ldob, yrbytes = 2u * (unsigned)d * ldyb;   // accumulator rows are 2 lattice pixels apart
     epilogue16c<MODE, MT, true>(p, acc, tile_ok, voff, rbytes, yoff, yrbytes, ec, s4, q4, ypre);
-    if (MODE == MODE_STATS || MODE == MODE_BNBWD || MODE == MODE_STATS_ADD) {
+    if (MODE == MODE_STATS || MODE == MODE_BNBWD) {
       // The per-tile sums are added up per WORKGROUP (gridDim.x is a multiple of nblocks, so a workgroup keeps its n-block
       // for all its tiles): one partial row per workgroup instead of one per tile -- at 8 x 512 x 512 that is 256-512 rows
       // instead of 8192, few enough for the BatchNorm finalisers to read directly (no colsum_stage launch in between).
@@ -414,7 +387,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
   load_consts(cur.nblk);
   zero_acc();
   {
-    if (NPB == 1) { issue_w(0, 0, 0, cur.nblk, true, cur.phy * 2 + cur.phx); issue_w(1, 1, 0, cur.nblk, true, cur.phy * 2 + cur.phx); }
+    if (NPB == 1) { issue_w(0, 0, 0, cur.nblk, true); issue_w(1, 1, 0, cur.nblk, true); }
 #pragma unroll
     for (int sl = 0; sl < PJ; ++sl) issue_slice(sl, 0, patch_base(cur, 0), patch_edges(cur, true));
     if (NPB == 2) { issue_w(0, 0, 0, cur.nblk, true); issue_w(1, 1, 0, cur.nblk, true); }
@@ -438,20 +411,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
       for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
         for (int g = 0; g < 2; ++g) ab[kx][g] = aoff[kx][g] + (NPB == 2 ? cbuf * PBUF : 0);
-      const int ph_c = cur.phy * 2 + cur.phx, ph_n = __builtin_amdgcn_readfirstlane(last_kc ? nxt.phy * 2 + nxt.phx : ph_c);
-      if (CMP) {
-        // tap (ty, tx) sits at patch position (by + ty, bx + tx): the column shift selects between the precomputed base
-        // sets (the XOR key is a function of the patch column), the row shift is a plain offset
-        const int ph = CMP == 1 ? ph_c : 3 - (kc >> q.kshift);          // CMP == 2: (by, bx) = (1 - phase_y, 1 - phase_x)
-        const int by = ph >> 1, bx = ph & 1;
 #pragma unroll
-        for (int tx = 0; tx < 2; ++tx)
-#pragma unroll
-          for (int g = 0; g < 2; ++g)             // (mask arithmetic: written as a select the compiler indexes a scratch copy of aoff)
-            ab[tx][g] = ((aoff[tx + 1][g] & -bx) | (aoff[tx][g] & (bx - 1))) + by * (LPW * 128);
-      }
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
+      for (int t = 0; t < 9; ++t) {
         // ---- wait for the weights of this step (and, at t = 0, the patch of this chunk) -------------------------------
         if (NPB == 2) {
           constexpr int nA = lat_nsl<PJ, SPT>(0);
@@ -475,24 +436,23 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
         if (INORM && t == 0) normalise_patch(cur, kc);       // the patch of this chunk has landed (every wave's pieces)
         // ---- prefetch: weights two steps ahead, patch slices of the next chunk -----------------------------------------
         auto issue = [&]() {
-          if (t < NT - 2) issue_w((t + 2) % NWS, t + 2, kc, cur.nblk, true, ph_c);
-          else issue_w((t + 2) % NWS, t + 2 - NT, kc_n, nblk_n, have_n, ph_n);
+          if (t < 7) issue_w((t + 2) % 3, t + 2, kc, cur.nblk, true);
+          else issue_w((t + 2) % 3, t + 2 - 9, kc_n, nblk_n, have_n);
           if (NPB == 2) {
 #pragma unroll
             for (int u = 0; u < SPT; ++u)
               if (t * SPT + u < PJ) issue_slice(t * SPT + u, cbuf ^ 1, pb_n, pe_n);
           }
-          if ((MODE == MODE_BNBWD || MODE == MODE_STATS_ADD) && t == YT && last_kc) {     // after this tap's DMAs: the y fetch is younger than W(q + 2)
+          if (MODE == MODE_BNBWD && t == YT && last_kc) {     // after this tap's DMAs: the y fetch is younger than W(q + 2)
             unsigned voff[MT], yoff[MT];
             item_offsets(cur, voff, yoff);
-            epi16_prefetch_y<MT>(p, yoff, 2u * (unsigned)dout * ldyb, ypre);
+            epi16_prefetch_y<MT>(p, yoff, 2u * (unsigned)d * ldyb, ypre);
           }
         };
-        if (CMP) compute_tap(t >> 1, t & 1, t, ab, issue);
-        else compute_tap(t / 3, t % 3, t % 3, ab, issue);
+        compute_tap(t / 3, t % 3, t % 3, ab, issue);
       }
       if (NPB == 1) {
-        raw_barrier();                            // every wave has issued the MFMAs of the last tap: the patch buffer is free
+        raw_barrier();                            // every wave has issued the MFMAs of tap 8: the patch buffer is free
 #pragma unroll
         for (int sl = 0; sl < PJ; ++sl) issue_slice(sl, 0, pb_n, pe_n);
       }
@@ -505,7 +465,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_lattice_kernel(const Ig
     if (nxt.nblk != cur.nblk) { load_consts(nxt.nblk); zero_acc(); }
     cur = nxt;
   }
-  if ((MODE == MODE_STATS || MODE == MODE_BNBWD || MODE == MODE_STATS_ADD) && tid < BN) {
+  if ((MODE == MODE_STATS || MODE == MODE_BNBWD) && tid < BN) {
     constexpr int nrow = (MODE == MODE_BNBWD) ? 3 : 2;
     const int nblk0 = first - (int)udiv((unsigned)first, q.mg_nblocks, (unsigned)q.nblocks) * q.nblocks;
     const int r0 = (first - nblk0) / q.nblocks;              // this workgroup's row; its n-block never changed
@@ -1090,54 +1050,5 @@ int launch_igemm_lattice(IgemmParams& p, hipStream_t stream) {
   if (p.in_scale) return launch_lattice_cfg<4, 1, 4, 1, MODE_STATS, true>(p, q, 2, stream);      // igemm_lattice_bnin_supported
   return launch_lattice_mode<4, 1, 4, 1>(p, q, 2, stream);
 }
-
-// ------------------------------------------------------------------------------------------------------------------------
-// Composed up-path (CMP forms of igemm_lattice_kernel, 64-channel n-blocks, two workgroups per CU).
-//   forward  (CMP 1): x = low-res tensor [nimg, Hi, Wi, Cin = 2C], out = the 2x finer stage output [nimg, 2 Hi, 2 Wi, Cout = C],
-//                     which already holds the other launch's partial sums (bn_y == out): MODE_STATS_ADD
-//   dgrad    (CMP 2): x = gradient of that output [nimg, 2 Ho, 2 Wo, Cin = C], out = low-res gradient [nimg, Ho, Wo, Cout = 2C]
-//                     + the fused BatchNorm-backward sums of the stage that produced the low-res tensor: MODE_BNBWD
-bool igemm_lattice_up_supported(int nimg, int hlo, int wlo, int clo, int chi, int ldlo, int ldhi) {
-  if (!lattice_enabled() || nimg <= 0) return false;
-  if (hlo % LTH != 0 || wlo % LTW != 0 || clo % 64 != 0 || chi % 64 != 0) return false;
-  if ((clo / 64) & (clo / 64 - 1) || (chi / 64) & (chi / 64 - 1)) return false;       // chunk counts: powers of two (phase << kshift)
-  if (512 % (clo / 64) != 0 || 512 % (chi / 64) != 0) return false;
-  const long plo = (long)nimg * hlo * wlo;
-  return plo * ldlo * 2 < (1L << 31) && 4 * plo * ldhi * 2 < (1L << 31) && 16L * clo * chi * 2 < (1L << 31);
-}
-
-template <int CMP>
-static int launch_lattice_up(IgemmParams& p, int hlo, int wlo, hipStream_t stream) {
-  constexpr int MODE = CMP == 1 ? MODE_STATS_ADD : MODE_BNBWD;
-  constexpr int NW = 4, BN = 64, PJ = (LPI + NW - 1) / NW;
-  constexpr int LDS = PJ * NW * 1024 + 4 * BN * 128 + NW * 128 * 4;            // 44 KB patch + 4 x 8 KB weight stages + 2 KB scratch
-  LatticeParams q{};
-  q.d = 2;
-  q.Hs = hlo; q.Ws = wlo;
-  q.tiles_x = wlo / LTW; q.tiles_y = hlo / LTH;
-  q.tiles_per_img = (CMP == 1 ? 4 : 1) * q.tiles_x * q.tiles_y;
-  const int nimg = (int)((long)p.M / ((long)p.Ho * p.Wo));
-  q.mtiles = nimg * q.tiles_per_img;                       // = M / 256
-  q.nkc = (CMP == 2 ? 4 : 1) * (p.Cin / 64);
-  for (q.kshift = 0; (1 << q.kshift) < p.Cin / 64; ++q.kshift) {}
-  q.nblocks = p.Cout / BN;
-  q.items = q.mtiles * q.nblocks;
-  const long grid = lattice_grid(q.items, 2);
-  if (grid % q.nblocks != 0) { set_error("igemm_lattice_up: grid %ld / nblocks %d", grid, q.nblocks); return UNETDC_ELAUNCH; }
-  q.stat_rows = (int)(grid / q.nblocks);
-  p.mblocks = q.stat_rows;
-  p.nblocks = q.nblocks;
-  auto magic = [](unsigned dv) { return dv <= 1 ? 0u : (unsigned)(((1ull << 32) + dv - 1) / dv); };
-  q.mg_nblocks = magic(q.nblocks); q.mg_tpi = magic(q.tiles_per_img); q.mg_tpp = magic(q.tiles_x * q.tiles_y);
-  q.mg_d = magic(q.d); q.mg_tx = magic(q.tiles_x);
-  p.mode = MODE;
-  if (const int rc_ = ensure_dynamic_lds(reinterpret_cast<const void*>(&igemm_lattice_kernel<4, 1, 4, 1, MODE, false, CMP>), LDS,
-                                         "igemm_lattice_kernel (composed up-path)")) return rc_;
-  hipLaunchKernelGGL((igemm_lattice_kernel<4, 1, 4, 1, MODE, false, CMP>), dim3((unsigned)grid), dim3(NW * 64), LDS, stream, p, q);
-  note_kernel(CMP == 1 ? "igemm_lattice_kernel<4, 1, 4, 1, 5> up-fwd" : "igemm_lattice_kernel<4, 1, 4, 1, 4> up-dgrad");
-  return check_launch("igemm_lattice_kernel (composed up-path)");
-}
-int launch_lattice_up_fwd(IgemmParams& p, int hlo, int wlo, hipStream_t stream) { return launch_lattice_up<1>(p, hlo, wlo, stream); }
-int launch_lattice_up_dgrad(IgemmParams& p, int hlo, int wlo, hipStream_t stream) { return launch_lattice_up<2>(p, hlo, wlo, stream); }
 
 }  // namespace unetdc

@@ -7,8 +7,7 @@ namespace unetdc {
 // MODE_BNBWD: plain store of a gradient tensor dA plus, fused, the per-channel partial sums of the
 // BatchNorm-backward reduction of the stage that consumes dA:  S1 = sum dA*[n>0], S2 = sum dA*[n>0]*xhat
 // with n = scale*y + shift, xhat = (y - mean)*rstd read from that stage's saved conv output y.
-enum { MODE_STORE = 0, MODE_STATS = 1, MODE_AFFINE_RELU = 2, MODE_SHUFFLE = 3, MODE_BNBWD = 4,
-       MODE_STATS_ADD = 5 };   // STATS with an addend: out = acc + bias + bn_y[pixel][channel] (the partial sums another launch left there)
+enum { MODE_STORE = 0, MODE_STATS = 1, MODE_AFFINE_RELU = 2, MODE_SHUFFLE = 3, MODE_BNBWD = 4 };
 #define UNETDC_EUNSUPPORTED (-4)
 
 struct IgemmParams {
@@ -44,25 +43,6 @@ bool igemm_lattice_supported(const IgemmParams& p, int dtype);      // igemm_lat
 int launch_igemm_lattice(IgemmParams& p, hipStream_t stream);
 bool igemm_lattice_bnin_supported(const IgemmParams& p, int dtype);  // x = raw conv output, BatchNorm + ReLU applied per staged patch
 bool igemm_lattice_bnin_writes_activation(const IgemmParams& p, int dtype);   // ... and that form can store the normalised activation
-// composed up-path (conv3x3 over the up half of the concat o convT2x2 as one operator on the low-res tensor, igemm_lattice.hip)
-bool igemm_lattice_up_supported(int nimg, int hlo, int wlo, int clo, int chi, int ldlo, int ldhi);
-int launch_lattice_up_fwd(IgemmParams& p, int hlo, int wlo, hipStream_t stream);
-int launch_lattice_up_dgrad(IgemmParams& p, int hlo, int wlo, hipStream_t stream);
-// upconv_compose.hip: the weight-side GEMMs and small passes of the composed up-path
-int launch_upc_compose(const void* w3_fwd, const void* w3_dgrad, const void* wt_dgrad, const float* w3_master, const float* b3,
-                       const float* bt, void* wc_fwd, void* wc_dgrad, void* wskip_fwd, void* wskip_dgrad, float* btab, int C,
-                       hipStream_t stream);
-int launch_upc_border_bias(void* y, int ldy, const float* btab, int N, int H, int W, int C, hipStream_t stream);
-int launch_upc_decompose(const void* dwb, const void* dwbt, const void* wt_fwd, const void* w3_dgrad, float* dw3, float* dwt, int C,
-                         hipStream_t stream);
-int launch_upc_dbt(const float* w3_master, const float* bt, const float* total, const void* dy, int lddy, float* bs_scratch, float* dw3,
-                   float* dbt, int N, int H, int W, int C, hipStream_t stream);
-int launch_upc_skip_scatter(const float* tmp, float* dw3, int C, hipStream_t stream);
-// upconv_wgrad.hip: the sixteen blocks of dW' (bf16, two layouts) from the low-res tensor and the gradient of decN.0's output
-bool upc_wgrad_supported(int N, int H, int W, int CI, int CJ, int ldx, int lddy);
-long upc_wgrad_workspace_bytes(int N, int H, int W, int CI, int CJ);
-int launch_upc_wgrad(const void* x, int ldx, const void* dy, int lddy, void* dwb, void* dwbt, void* workspace, long workspace_bytes,
-                     int N, int H, int W, int CI, int CJ, hipStream_t stream);
 bool igemm_dma16_supported(const IgemmParams& p, int dtype);
 int launch_igemm_dma16(IgemmParams& p, int cfg, hipStream_t stream);
 
