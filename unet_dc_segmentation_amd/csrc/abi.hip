@@ -129,7 +129,8 @@ int unetdc_conv3x3_fwd_bnin(const void* x_raw, int ldx, const float* in_scale, c
   GEOM_CHECK(n, h, w);
   UNETDC_REQUIRE(dilation >= 1 && ldx >= cin && ldy >= cout, "conv3x3_fwd_bnin: bad dilation/ld");
   UNETDC_REQUIRE(in_scale && in_shift && stats_part, "conv3x3_fwd_bnin: null pointer");
-  UNETDC_REQUIRE(act_out == nullptr || (ldact >= cin && ldact % 8 == 0), "conv3x3_fwd_bnin: bad activation ld");
+  UNETDC_REQUIRE(act_out == nullptr || (ldact >= cin && ldact % 8 == 0 && (int64_t)n * h * w * ldact * 2 < (1LL << 32)),
+                 "conv3x3_fwd_bnin: bad activation ld (or an activation tensor of 4 GiB and more)");
   IgemmParams p{};
   p.act_out = act_out; p.ld_act = ldact;
   p.x = x_raw; p.w = w_fwd; p.out = y; p.bias = bias; p.stats = stats_part; p.in_scale = in_scale; p.in_shift = in_shift;
