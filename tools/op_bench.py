@@ -53,12 +53,16 @@ if op in ("fwd_bnin", "dgrad_bnstats", "wgrad_bnin"):
     wws_bytes = _lib.load().unetdc_conv3x3_wgrad_workspace(n, h, w, cin, cout, DTI)
     wws = G.workspace(wws_bytes)
     dwt = torch.empty(cout, cin, 3, 3, device="cuda")
+    # 128-channel n-blocks: the input-normalising forward also stores the normalised activation (what the engine asks of it)
+    act = torch.empty(n * h * w, cin, dtype=G.TD[dtype], device="cuda") \
+        if op == "fwd_bnin" and _lib.load().unetdc_conv3x3_bnin_supported(n, h, w, cin, cout, d, DTI) == 2 else None
 
 
 def run():
     if op == "fwd_bnin":
         _lib.call("unetdc_conv3x3_fwd_bnin", x.data_ptr(), cin, sc_in.data_ptr(), sh_in.data_ptr(), wf.data_ptr(), bias.data_ptr(),
-                  y.data_ptr(), cout, stats.data_ptr(), None, None, 0, n, h, w, cin, cout, d, DTI, G.stream())
+                  y.data_ptr(), cout, stats.data_ptr(), None, None if act is None else act.data_ptr(), 0 if act is None else cin,
+                  n, h, w, cin, cout, d, DTI, G.stream())
     elif op == "dgrad_bnstats":
         _lib.call("unetdc_conv3x3_dgrad_bnstats", dy.data_ptr(), cout, wd.data_ptr(), dx.data_ptr(), cin, yprev.data_ptr(), cin,
                   sc_in.data_ptr(), sh_in.data_ptr(), mu_in.data_ptr(), rs_in.data_ptr(), stats.data_ptr(), stats.numel(),
