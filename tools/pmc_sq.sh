@@ -16,3 +16,5 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
   rocprofv3 --output-format csv --pmc $set -d $out/$n -o p -- python3 tools/op_bench.py "$@" 3 > $out/$n.log 2>&1 || { echo "pass failed: $set"; tail -5 $out/$n.log; }
 done
 python3 tools/summarize_sq.py $out "$tag" "$*"
+# keep the summary only: the raw counter CSVs of five passes are tens of MB per kernel (gpurun merges at most 64 MiB back)
+find $out -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
