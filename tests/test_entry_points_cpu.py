@@ -246,6 +246,26 @@ def test_bench_roofline_bookkeeping():
     assert h1 == h2 and len(h1) == 16
 
 
+def test_bench_pmc_traffic_lookup_matches_full_template_arguments(tmp_path, monkeypatch):
+    """bench.pmc_traffic: the C ABI reports "igemm_lattice_wide_kernel<1>" (+ " bnin"), rocprofv3 prints the full template argument
+    list; a traffic file measured on OTHER kernel sources (stamp mismatch) is never used."""
+    import json
+
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    table = {"void unetdc::igemm_lattice_wide_kernel<1, false>(unetdc::IgemmParams, unetdc::LatticeParams)": {"bytes_corrected": 111.0},
+             "void unetdc::igemm_lattice_wide_kernel<1, true>(unetdc::IgemmParams, unetdc::LatticeParams)": {"bytes_corrected": 222.0},
+             "void unetdc::igemm_dma16_kernel<2, 4, 8, 2>(unetdc::IgemmParams)": {"bytes_corrected": 333.0}}
+    (prof / "r05_pmc_traffic.json").write_text(json.dumps({"kernel_source_sha16": bench.kernel_source_hash(), "kernels": table}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.pmc_traffic("igemm_lattice_wide_kernel<1>") == 111.0
+    assert bench.pmc_traffic("igemm_lattice_wide_kernel<1> bnin") == 222.0
+    assert bench.pmc_traffic("igemm_dma16_kernel<2, 4, 8>") is None or bench.pmc_traffic("igemm_dma16_kernel<2, 4, 8, 2>") == 333.0
+    (prof / "r05_pmc_traffic.json").write_text(json.dumps({"kernel_source_sha16": "0" * 16, "kernels": table}))
+    assert bench.pmc_traffic("igemm_lattice_wide_kernel<1>") is None
+
+
 def test_bench_timed_region_has_no_collector_pass_and_no_per_call_events():
     """bench.timed_region (the function the headline number comes from, run here with host-clock stand-ins for the HIP events):
     the cyclic collector is frozen + disabled for the region (no generation-2 pass can land in a step; the step below builds
